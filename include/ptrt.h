@@ -1,0 +1,262 @@
+/*
+ * ptrt.h -- C ABI of the MI355X (gfx950) path-tracing back end.
+ *
+ * This is the drop-in boundary for ONE hot path of Mark-Rindler/PTRT-game-engine:
+ * the per-pixel path-tracing render loop behind `Scene::render_to_device`
+ * (reference: src/pathtracer/scene/scene.cuh:1028-1209, kernel
+ * src/pathtracer/scene/scene_kernels.cuh:122-194).  Every entry point below
+ * names the reference interface it replaces.  Signatures are plain C: pointers,
+ * sizes, ints.  No HIP, torch or C++ types cross this boundary.
+ *
+ * All functions returning `int` return PTRT_OK (0) on success or a negative
+ * PTRT_E_* code; `ptrt_last_error(ctx)` gives the text.  The library never
+ * falls back to a CPU implementation: with no usable HIP device every call that
+ * needs one fails with PTRT_E_NO_DEVICE.
+ *
+ * Conventions shared with the reference:
+ *   - HDR / G-buffers are row-major, y = 0 is the TOP of the view
+ *     (scene_kernels.cuh:130-136); the RGB8 image is BOTTOM-UP, kernel row y is
+ *     written to byte row H-1-y (scene.cuh:2013-2015).
+ *   - material index == mesh index (path_logic.cuh:818-820).
+ *   - one random stream per pixel, keyed by the GLOBAL pixel index y*W+x
+ *     (scene_kernels.cuh:33-34), so a tile of a frame renders bit-identically
+ *     to the same rows of the full frame.
+ */
+#ifndef PTRT_H
+#define PTRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTRT_ABI_VERSION 1
+
+enum {
+    PTRT_OK = 0,
+    PTRT_E_INVALID = -1,   /* bad argument / inconsistent scene arrays        */
+    PTRT_E_NO_DEVICE = -2, /* no HIP device or device index out of range      */
+    PTRT_E_HIP = -3,       /* a HIP runtime call failed                       */
+    PTRT_E_NOT_READY = -4, /* render before geometry/materials were uploaded  */
+    PTRT_E_NOMEM = -5
+};
+
+/* ---- plain-data mirrors of the reference's device structs ---------------- */
+
+typedef struct ptrt_vec3 { float x, y, z; } ptrt_vec3; /* common/vec3.cuh:8 (12 B) */
+
+/* DeviceBVHNode, pathtracer/scene/mesh.cuh:37-43 (40 B).  Inner node: count==0,
+ * left/right = child node indices.  Leaf: count>0, start = first slot in the
+ * primitive-index array. */
+typedef struct ptrt_bvh_node {
+    ptrt_vec3 bmin, bmax;
+    int32_t left, right, start, count;
+} ptrt_bvh_node;
+
+typedef struct ptrt_tri { int32_t v0, v1, v2; } ptrt_tri; /* mesh.cuh:45-47 */
+
+/* Host-side description of one mesh: what DeviceMesh (math/intersection.cuh:90-106)
+ * holds, with host pointers.  Matrices are the 16 floats of the reference's
+ * mat4 exactly as Transform3D::updateMatrices leaves them
+ * (scene/transform.cuh:260-306); the path reads them as ROW-major 3x4
+ * (intersection.cuh:258-281). */
+typedef struct ptrt_mesh_desc {
+    const ptrt_vec3 *verts;
+    int32_t vert_count;
+    const ptrt_tri *faces;
+    int32_t face_count;
+    const ptrt_bvh_node *nodes; /* BLAS, pre-order, node 0 = root */
+    int32_t node_count;
+    const int32_t *prim_indices; /* leaf slots -> face index */
+    int32_t prim_count;
+    float world[16];
+    float inverse[16];
+    float normal[16];
+    int32_t has_transform; /* scene.cuh:718-721 */
+} ptrt_mesh_desc;
+
+/* Light, pathtracer/scene/lights.cuh:14-26 (60 B, same field order). */
+enum { PTRT_LIGHT_POINT = 0, PTRT_LIGHT_DIRECTIONAL = 1, PTRT_LIGHT_SPOT = 2 };
+typedef struct ptrt_light {
+    int32_t type;
+    ptrt_vec3 position, direction, color;
+    float intensity, range;
+    float inner_cone, outer_cone; /* COSINES of the half angles (scene.cuh:1539-1540) */
+    float radius;
+} ptrt_light;
+
+/* The ray-generation part of Camera (scene/camera.cuh:32-39). */
+typedef struct ptrt_camera {
+    ptrt_vec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+    float lens_radius;
+} ptrt_camera;
+
+/* DeviceMaterials, scene/material_lib.cuh:107-125: struct of 17 arrays, each
+ * `count` long (host pointers here). */
+typedef struct ptrt_materials {
+    const ptrt_vec3 *albedo;
+    const ptrt_vec3 *specular;
+    const float *metallic;
+    const float *roughness;
+    const ptrt_vec3 *emission;
+    const float *ior;
+    const float *transmission;
+    const float *transmission_roughness;
+    const float *clearcoat;
+    const float *clearcoat_roughness;
+    const ptrt_vec3 *subsurface_color; /* carried, unused by the path */
+    const float *subsurface_radius;    /* carried, unused by the path */
+    const float *anisotropy;           /* carried, unused by the path */
+    const float *sheen;
+    const ptrt_vec3 *sheen_tint;
+    const float *iridescence;
+    const float *iridescence_thickness;
+    int32_t count;
+} ptrt_materials;
+
+/* Everything `path_trace_kernel` receives that is not a frame buffer
+ * (scene_kernels.cuh:123-129), flattened, host pointers. */
+typedef struct ptrt_scene_desc {
+    const ptrt_mesh_desc *meshes;
+    int32_t mesh_count;
+    const ptrt_bvh_node *tlas_nodes;
+    int32_t tlas_node_count;
+    const int32_t *tlas_mesh_indices;
+    int32_t tlas_index_count;
+    ptrt_materials materials;
+    const ptrt_light *lights;
+    int32_t light_count;
+    ptrt_camera camera;
+    ptrt_vec3 sky_top, sky_bottom;
+    int32_t use_sky;
+} ptrt_scene_desc;
+
+/* HitInfo, math/intersection.cuh:108-124, as returned by Scene::traceSingleRay. */
+typedef struct ptrt_hit {
+    int32_t hit;
+    float t;
+    ptrt_vec3 point, normal;
+    int32_t mesh_index;
+    int32_t front_face;
+    float u, v;
+    int32_t face_index;
+    ptrt_vec3 local_point;
+} ptrt_hit;
+
+/* Per-frame counters of the trace stage (Mrays/s numerator). */
+typedef struct ptrt_stats {
+    uint64_t extension_rays; /* traceRay calls   (intersection.cuh:526) */
+    uint64_t shadow_rays;    /* bvh_any_hit_tlas (intersection.cuh:481) */
+    uint64_t paths;          /* pixel-samples started                   */
+} ptrt_stats;
+
+#define PTRT_BLUE_NOISE_SIZE 64 /* common/bluenoise.cuh: 64 x 64 x 2 floats */
+#define PTRT_BLUE_NOISE_FLOATS (PTRT_BLUE_NOISE_SIZE * PTRT_BLUE_NOISE_SIZE * 2)
+#define PTRT_DEFAULT_SEED 12345ULL /* scene.cuh:448 */
+
+/* buffer kinds for ptrt_read_buffer / ptrt_device_buffer (tile rows only) */
+enum {
+    PTRT_BUF_ACCUM = 0,     /* float[rows*W*3]  HDR radiance, Scene::getNoisyColorBuffer (scene.cuh:1722) */
+    PTRT_BUF_NORMAL = 1,    /* float[rows*W*3]  first-hit normal, getNormalBuffer (scene.cuh:1723)         */
+    PTRT_BUF_DEPTH = 2,     /* float[rows*W]    first-hit t,      getDepthBuffer  (scene.cuh:1724)         */
+    PTRT_BUF_OBJECT_ID = 3, /* int32[rows*W]    first-hit mesh index (scene_kernels.cuh:193)               */
+    PTRT_BUF_RGB8 = 4,      /* uint8[rows*W*3]  tonemapped tile, bottom-up WITHIN the tile                 */
+    PTRT_BUF_RNG = 5        /* uint32[rows*W*6] generator state {d, v0..v4} per pixel (canonical order)     */
+};
+
+typedef struct ptrt_ctx ptrt_ctx;
+
+/* Scene::Scene(w,h) (scene.cuh:747-832): allocates frame buffers and the per-pixel
+ * generator states on HIP device `device`.  The context renders rows
+ * [tile_y0, tile_y0+tile_rows) of a full_w x full_h frame (tile_rows <= 0 means
+ * the whole frame).  Installs nothing else: blue noise, RNG seed, scene are
+ * separate calls. */
+int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, ptrt_ctx **out);
+
+/* Scene::~Scene (scene.cuh:834-941).  NULL and repeated destroy of a dead handle's
+ * slot are tolerated the way the reference tolerates double cudaFree. */
+void ptrt_destroy(ptrt_ctx *ctx);
+
+const char *ptrt_last_error(const ptrt_ctx *ctx); /* never NULL */
+int ptrt_abi_version(void);
+
+/* initBlueNoise() -> cudaMemcpyToSymbol(d_blue_noise) (common/bluenoise.cuh:189-198).
+ * `table` = 64*64*2 floats, [y][x][channel]. */
+int ptrt_set_blue_noise(ptrt_ctx *ctx, const float *table);
+
+/* Scene::initRandomStates + init_curand_kernel (scene.cuh:433-456,
+ * scene_kernels.cuh:26-35): XORWOW state for every pixel of the tile,
+ * seed `seed`, subsequence = global pixel index, offset 0. */
+int ptrt_reset_rng(ptrt_ctx *ctx, unsigned long long seed);
+
+/* Mesh::upload + Mesh::uploadBVH + Scene::buildAndUploadTLAS's copies + the
+ * DeviceMesh descriptor upload (mesh.cuh:330-346,499-516; scene.cuh:458-594,
+ * 684-727).  Host arrays are copied (and re-laid-out for the GPU) before return. */
+int ptrt_upload_geometry(ptrt_ctx *ctx, const ptrt_mesh_desc *meshes, int mesh_count,
+                         const ptrt_bvh_node *tlas_nodes, int tlas_node_count,
+                         const int32_t *tlas_mesh_indices, int tlas_index_count);
+
+/* Scene::uploadMaterialSoA (scene.cuh:286-431). */
+int ptrt_upload_materials(ptrt_ctx *ctx, const ptrt_materials *mats);
+
+/* the d_lights upload in Scene::updateAccelerationStructures (scene.cuh:636-651). */
+int ptrt_upload_lights(ptrt_ctx *ctx, const ptrt_light *lights, int light_count);
+
+/* `Camera cam` kernel argument (scene_kernels.cuh:124), set by Scene::setCamera (scene.cuh:1298). */
+int ptrt_set_camera(ptrt_ctx *ctx, const ptrt_camera *cam);
+
+/* Scene::setSkyGradient / disableSky (scene.cuh:1548-1565). */
+int ptrt_set_sky(ptrt_ctx *ctx, const ptrt_vec3 *top, const ptrt_vec3 *bottom, int use_sky);
+
+/* convenience: the five uploads above from one flattened description */
+int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);
+
+/* The body of Scene::render_to_device (scene.cuh:1028-1209) with denoiser, bloom
+ * and upscale off: path_trace_kernel then tonemap_kernel for this context's
+ * tile.  `frame_index` is the reference's frame_count_ (jitter index frame+s,
+ * scene_kernels.cuh:152-157).  `out_rgb8`: tile_rows*W*3 bytes, bottom-up within
+ * the tile; a DEVICE pointer if out_is_device != 0 (the mapped PBO of
+ * glfw_view_interop.hpp:281), else a host buffer (synchronous copy).  NULL skips
+ * the copy (the RGB8 image stays readable through PTRT_BUF_RGB8).
+ * Asynchronous w.r.t. the host when out_is_device != 0 or out_rgb8 == NULL, like
+ * the reference (it returns right after the tonemap launch). */
+int ptrt_render(ptrt_ctx *ctx, int frame_index, int spp, int max_depth, void *out_rgb8,
+                int out_is_device);
+
+/* cudaDeviceSynchronize at the call sites that have one (scene.cuh:455,1244). */
+int ptrt_sync(ptrt_ctx *ctx);
+
+/* synchronising read-back of one tile buffer into host memory */
+int ptrt_read_buffer(ptrt_ctx *ctx, int kind, void *host_dst, size_t dst_bytes);
+
+/* Scene::getNoisyColorBuffer/getNormalBuffer/getDepthBuffer (scene.cuh:1722-1725):
+ * raw device pointer of a tile buffer (NULL on error).  PTRT_BUF_RNG is not
+ * exposed this way (its device layout is private). */
+void *ptrt_device_buffer(ptrt_ctx *ctx, int kind);
+
+/* write generator states back in canonical order (tests / checkpointing) */
+int ptrt_write_rng(ptrt_ctx *ctx, const uint32_t *states, size_t bytes);
+
+/* Scene::traceSingleRay -> trace_single_ray_kernel (scene.cuh:1367-1391,
+ * scene_kernels.cuh:38-49); batched: n rays, origins/directions as n*3 floats. */
+int ptrt_trace_rays(ptrt_ctx *ctx, const float *origins, const float *directions, int n,
+                    ptrt_hit *out_hits);
+
+/* counters accumulated by ptrt_render since the last call (reset on read);
+ * only maintained when ptrt_set_option(ctx,"count_rays",1). */
+int ptrt_get_stats(ptrt_ctx *ctx, ptrt_stats *out);
+
+/* tuning / diagnostics knobs, by name; unknown names return PTRT_E_INVALID */
+int ptrt_set_option(ptrt_ctx *ctx, const char *name, long long value);
+
+/* duration in milliseconds of the last ptrt_render's path-trace kernel and
+ * tonemap kernel, measured with HIP events on the context's stream
+ * (synchronises).  Either pointer may be NULL. */
+int ptrt_last_kernel_ms(ptrt_ctx *ctx, float *trace_ms, float *tonemap_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRT_H */

@@ -1,0 +1,154 @@
+/*
+ * oracle/detmath.h -- TEST INFRASTRUCTURE (part of the CPU oracle; never linked
+ * into the product).
+ *
+ * Deterministic fp32 elementary functions built only from IEEE-754 operations
+ * that are correctly rounded on both x86-64 and gfx950: + - * / sqrt, fused
+ * multiply-add, round-to-nearest-even, and integer bit manipulation.  The HIP
+ * kernels carry their own copy of the same algorithms
+ * (ptrt-game-engine_amd/csrc/det_math.hip.h); tests/test_detmath_gpu.py checks
+ * the two bit for bit, tests/test_detmath.py checks this file against glibc.
+ *
+ * They stand in for the CUDA libm calls on the reference's path
+ * (sinf/cosf: math/sampling.cuh:115,155,201 and rendering/pbr_utils.cuh:120;
+ *  expf/logf: rendering/pbr_utils.cuh:149-161 via path_logic.cuh:826-828;
+ *  powf: scene/scene.cuh:2031-2039).  CUDA's own results for these differ from
+ * glibc's and from ROCm's by ulps, so no choice of libm reproduces the CUDA
+ * binary; choosing one arithmetic for oracle AND kernel is what makes the
+ * radiance comparison exact instead of statistical.  Accuracy: <= 2 ulp on the
+ * ranges the path uses (measured in tests/test_detmath.py).
+ */
+#ifndef PTRT_ORACLE_DETMATH_H
+#define PTRT_ORACLE_DETMATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline float dm_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+static inline uint32_t dm_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+static inline float dm_float(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* CUDA fmaxf/fminf semantics (a NaN operand is ignored); the sign of a zero
+ * result is "second operand on ties", identical in the kernel copy. */
+static inline float dm_max(float a, float b) { return (a > b || b != b) ? a : b; }
+static inline float dm_min(float a, float b) { return (a < b || b != b) ? a : b; }
+
+/* sin and cos of x (radians), |x| up to a few thousand. */
+static inline void dm_sincos(float x, float *s_out, float *c_out) {
+    const float kf = rintf(x * 0x1.45f306p-1f); /* 2/pi */
+    const int k = (int)kf;
+    float r = dm_fma(-kf, 0x1.921fb6p+0f, x); /* pi/2 in three pieces */
+    r = dm_fma(-kf, -0x1.777a5cp-25f, r);
+    r = dm_fma(-kf, -0x1.ee59dap-50f, r);
+    const float r2 = r * r;
+    float sp = dm_fma(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = dm_fma(sp, r2, -1.6666654611e-1f);
+    const float sn = dm_fma(sp * r2, r, r);
+    float cp = dm_fma(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = dm_fma(cp, r2, 4.166664568298827e-2f);
+    const float cs = dm_fma(cp, r2 * r2, dm_fma(-0.5f, r2, 1.0f));
+    float s, c;
+    switch (k & 3) {
+    case 0: s = sn; c = cs; break;
+    case 1: s = cs; c = -sn; break;
+    case 2: s = -sn; c = -cs; break;
+    default: s = -cs; c = sn; break;
+    }
+    *s_out = s;
+    *c_out = c;
+}
+static inline float dm_sin(float x) {
+    float s, c;
+    dm_sincos(x, &s, &c);
+    return s;
+}
+static inline float dm_cos(float x) {
+    float s, c;
+    dm_sincos(x, &s, &c);
+    return c;
+}
+
+/* e^x */
+static inline float dm_exp(float x) {
+    if (x != x)
+        return x;
+    if (x > 88.72283f)
+        return dm_float(0x7f800000u);
+    if (x < -104.0f)
+        return 0.0f;
+    const float kf = rintf(x * 0x1.715476p+0f); /* log2(e) */
+    float r = dm_fma(-kf, 0x1.62e4p-1f, x);     /* ln2 hi (few bits: k*hi exact) */
+    r = dm_fma(-kf, 0x1.7f7d1cp-20f, r);        /* ln2 lo */
+    float p = 1.9875691500e-4f;
+    p = dm_fma(p, r, 1.3981999507e-3f);
+    p = dm_fma(p, r, 8.3334519073e-3f);
+    p = dm_fma(p, r, 4.1665795894e-2f);
+    p = dm_fma(p, r, 1.6666665459e-1f);
+    p = dm_fma(p, r, 5.0000001201e-1f);
+    p = dm_fma(p, r * r, r) + 1.0f;
+    const int k = (int)kf;         /* -150 .. 128 */
+    const int k1 = k >> 1;         /* arithmetic shift */
+    const int k2 = k - k1;
+    const float s1 = dm_float((uint32_t)(k1 + 127) << 23);
+    const float s2 = dm_float((uint32_t)(k2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+/* natural log; x <= 0 follows IEEE (log 0 = -inf, log negative = NaN) */
+static inline float dm_log(float x) {
+    if (x != x)
+        return x;
+    if (x < 0.0f)
+        return dm_float(0x7fc00000u);
+    if (x == 0.0f)
+        return dm_float(0xff800000u);
+    uint32_t u = dm_bits(x);
+    if (u == 0x7f800000u)
+        return x;
+    int e = 0;
+    if (u < 0x00800000u) { /* denormal: scale by 2^23 */
+        x = x * 8388608.0f;
+        u = dm_bits(x);
+        e = -23;
+    }
+    e += (int)(u >> 23) - 126;                               /* x = m * 2^e, m in [0.5,1) */
+    float m = dm_float((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) {
+        e -= 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = dm_fma(y, m, -1.1514610310e-1f);
+    y = dm_fma(y, m, 1.1676998740e-1f);
+    y = dm_fma(y, m, -1.2420140846e-1f);
+    y = dm_fma(y, m, 1.4249322787e-1f);
+    y = dm_fma(y, m, -1.6668057665e-1f);
+    y = dm_fma(y, m, 2.0000714765e-1f);
+    y = dm_fma(y, m, -2.4999993993e-1f);
+    y = dm_fma(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    const float fe = (float)e;
+    y = dm_fma(fe, -2.12194440e-4f, y);
+    y = dm_fma(-0.5f, z, y);
+    float r = m + y;
+    r = dm_fma(fe, 0.693359375f, r);
+    return r;
+}
+
+/* x^y for x > 0 (the only use on the path: the sRGB OETF, x in (0.003,1]) */
+static inline float dm_pow(float x, float y) { return dm_exp(y * dm_log(x)); }
+
+#endif

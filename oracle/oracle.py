@@ -1,0 +1,139 @@
+"""ctypes binding of the CPU oracle (oracle/libptrt_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  PARITY UNPINNED (see ptrt_oracle.cpp header).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptrt_oracle.so")
+
+
+def build():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+if not os.path.exists(LIB_PATH):
+    build()
+lib = C.CDLL(LIB_PATH)
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("tile_y0", C.c_int32), ("tile_rows", C.c_int32),
+                ("spp", C.c_int32), ("max_depth", C.c_int32), ("frame_count", C.c_int32), ("threads", C.c_int32),
+                ("blue_noise", C.POINTER(C.c_float)), ("rng", C.POINTER(C.c_uint32)),
+                ("accum", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)), ("depth", C.POINTER(C.c_float)),
+                ("object_id", C.POINTER(C.c_int32)),
+                ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64)]
+
+
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint32)
+lib.oracle_has_fma.restype = C.c_int
+lib.oracle_xorwow_init.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, _up]
+lib.oracle_xorwow_custom.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_int, _up, _up]
+lib.oracle_xorwow_draw.argtypes = [_up, C.c_int, _up, _fp]
+lib.oracle_render.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
+lib.oracle_render.restype = C.c_int
+lib.oracle_tonemap.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+lib.oracle_trace_rays.argtypes = [C.c_void_p, _fp, _fp, C.c_int, C.c_void_p]
+lib.oracle_any_hit.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int, C.POINTER(C.c_int32)]
+lib.oracle_detmath.argtypes = [C.c_int, _fp, _fp, C.c_int, _fp]
+lib.oracle_eval_bsdf.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp]
+lib.oracle_scatter.argtypes = [C.c_void_p, C.c_int, _fp, _fp, C.c_int, _up, _fp]
+
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3),
+                      ("mesh_index", "<i4"), ("front_face", "<i4"), ("u", "<f4"), ("v", "<f4"),
+                      ("face_index", "<i4"), ("local_point", "<f4", 3)])
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _u(a):
+    return a.ctypes.data_as(_up)
+
+
+def xorwow_init(seed, first, count):
+    out = np.zeros((count, 6), dtype=np.uint32)
+    lib.oracle_xorwow_init(seed, first, count, _u(out))
+    return out
+
+
+def xorwow_custom(seed, subsequence, consts, n_draws):
+    draws = np.zeros(max(n_draws, 1), dtype=np.uint32)
+    state = np.zeros(6, dtype=np.uint32)
+    lib.oracle_xorwow_custom(seed, subsequence, consts[0], consts[1], consts[2], consts[3], n_draws, _u(draws),
+                             _u(state))
+    return draws[:n_draws], state
+
+
+def xorwow_draw(state6, n, uniform=False):
+    st = np.array(state6, dtype=np.uint32).copy()
+    if uniform:
+        out = np.zeros(n, dtype=np.float32)
+        lib.oracle_xorwow_draw(_u(st), n, None, _f(out))
+    else:
+        out = np.zeros(n, dtype=np.uint32)
+        lib.oracle_xorwow_draw(_u(st), n, _u(out), None)
+    return out, st
+
+
+def render(scene_desc_ptr, width, height, spp, max_depth, frame_count, blue_noise, rng, tile_y0=0, tile_rows=0,
+           threads=1):
+    """path_trace_kernel on the CPU.  `rng` (rows*W,6) uint32 is advanced in place.
+    Returns dict(accum, normal, depth, object_id, stats)."""
+    rows = tile_rows if tile_rows > 0 else height
+    n = rows * width
+    assert rng.shape == (n, 6) and rng.dtype == np.uint32 and rng.flags.c_contiguous
+    bn = np.ascontiguousarray(blue_noise, dtype=np.float32)
+    out = dict(accum=np.zeros((n, 3), np.float32), normal=np.zeros((n, 3), np.float32),
+               depth=np.zeros(n, np.float32), object_id=np.zeros(n, np.int32))
+    a = RenderArgs(width, height, tile_y0, rows, spp, max_depth, frame_count, threads, _f(bn), _u(rng),
+                   _f(out["accum"]), _f(out["normal"]), _f(out["depth"]),
+                   out["object_id"].ctypes.data_as(C.POINTER(C.c_int32)), 0, 0, 0)
+    rc = lib.oracle_render(C.cast(scene_desc_ptr, C.c_void_p), C.byref(a))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render failed ({rc}); -2 means the CPU lacks FMA")
+    out["stats"] = dict(extension_rays=a.extension_rays, shadow_rays=a.shadow_rays, paths=a.paths)
+    return out
+
+
+def tonemap(accum, width, rows, threads=1):
+    acc = np.ascontiguousarray(accum, dtype=np.float32)
+    out = np.zeros((rows, width, 3), dtype=np.uint8)
+    lib.oracle_tonemap(_f(acc), width, rows, 1, out.ctypes.data_as(C.c_void_p), threads)
+    return out
+
+
+def trace_rays(scene_desc_ptr, origins, directions):
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(o.shape[0], dtype=HIT_DTYPE)
+    lib.oracle_trace_rays(C.cast(scene_desc_ptr, C.c_void_p), _f(o), _f(d), o.shape[0],
+                          out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def any_hit(scene_desc_ptr, origins, directions, tmax):
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tmax, dtype=np.float32)
+    out = np.zeros(o.shape[0], dtype=np.int32)
+    lib.oracle_any_hit(C.cast(scene_desc_ptr, C.c_void_p), _f(o), _f(d), _f(t), o.shape[0],
+                       out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
+def detmath(op, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib.oracle_detmath(op, _f(x), _f(y), x.size, _f(out))
+    return out

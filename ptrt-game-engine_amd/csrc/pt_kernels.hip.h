@@ -1,0 +1,959 @@
+// pt_kernels.hip.h -- gfx950 kernels of the path tracer.
+//
+//   path_trace_kernel<GEOM,FULL>  the per-pixel render loop: primary-ray generation,
+//        two-level BVH closest hit, shading + next-event estimation (shadow any-hit),
+//        BSDF sampling, Russian roulette, sample accumulation, G-buffer, RNG
+//        write-back and the tonemap, in ONE launch.
+//        (reference: path_trace_kernel scene_kernels.cuh:122-194 -> tracePath
+//        path_logic.cuh:782-899 -> traceRay intersection.cuh:526-605, and
+//        tonemap_kernel scene.cuh:2004-2047)
+//   xorwow_init_kernel            init_curand_kernel (scene_kernels.cuh:26-35)
+//   trace_rays_kernel             trace_single_ray_kernel (scene_kernels.cuh:38-49), batched
+//
+// Execution model (MI355X-first, not the reference's 8x8 CUDA block of 2 warps):
+//   * one 64-lane wavefront = one 8x8 pixel tile = one workgroup; lanes keep their
+//     pixel for the whole frame because the per-pixel XORWOW stream is strictly
+//     sequential across samples and bounces.
+//   * persistent lanes with path regeneration: a lane whose path ends starts its
+//     next sample immediately instead of idling until the slowest lane of the wave
+//     finishes the bounce loop.
+//   * scene data is re-laid-out at upload: child-pair 64-byte BVH nodes (one fetch
+//     per inner node gives both child boxes), 48-byte triangle packets
+//     {v0|face, e1, e2} in leaf order (no index indirections), 96-byte material and
+//     64-byte light records, all float4-aligned.
+//   * wave-uniform data (mesh records, single-leaf triangle packets, lights,
+//     materials of a uniform mesh) is addressed through readfirstlane'd indices so
+//     the compiler fetches it with scalar loads into SGPRs.
+//   * per-lane traversal stacks live in LDS, [depth][lane] layout (ds_*_b64,
+//     conflict-free), sized by the scene's real BVH depth.
+//
+// Equivalences used (each keeps results bit-identical to the literal algorithm;
+// proofs in DESIGN.md "Traversal equivalences"):
+//   E1 the reference re-tests a node's own box when it becomes current; for the
+//      near child that test repeats the one just made, for a popped far child it
+//      reduces to `entry < best.t`, so the stack carries the entry distance.
+//   E2 the slab test's early-out after the y slab never changes the result.
+//   E3 one running closest hit with strict `<` over (mesh order, leaf order) equals
+//      per-mesh closest followed by strict `<` across meshes, for untransformed
+//      meshes (transformed ones keep a separate local-space best).
+//   E4 any-hit is order independent as long as the same boxes gate the same
+//      triangles; BVHs deeper than 23 levels are rejected at upload, so the
+//      reference's 24-entry stack-overflow drop can never trigger.
+#pragma once
+#include "pt_device.hip.h"
+
+namespace pt {
+
+struct Camera {
+    f3 origin, llc, horizontal, vertical, u, v, w;
+    float lens_radius;
+};
+
+// Everything the kernels read, by value in the kernarg segment.
+struct KParams {
+    // scene arena (device pointers)
+    const float4 *mesh_recs;  // 12 float4 per mesh
+    const float4 *nodes;      // 4 float4 per inner node (child pair)
+    const int2 *leaves;       // {first tri slot, count}
+    const float4 *tris;       // 3 float4 per leaf slot
+    const float4 *tlas_nodes; // child-pair nodes over meshes
+    const int2 *tlas_leaves;  // {first index into tlas_mesh_ids, count}
+    const int *tlas_mesh_ids;
+    const float4 *materials; // 6 float4 per mesh
+    const float4 *lights;    // 4 float4 per light
+    const float2 *blue_noise; // 64*64
+    float tlas_root_min[3], tlas_root_max[3];
+    int tlas_root_ref; // >=0 inner node, <0 ~leaf
+    int n_meshes, n_lights;
+    int stack_entries; // LDS stack depth per lane (BLAS)
+    // frame
+    Camera cam;
+    f3 sky_top, sky_bottom;
+    int use_sky;
+    int width, height; // full frame
+    int y0, rows;      // tile
+    int tiles_x;
+    int spp, max_depth, frame_count;
+    // buffers (tile-sized)
+    uint32_t *rng; // 6 planes of rows*width
+    float *accum, *normal, *depth;
+    int *object_id;
+    unsigned char *rgb8;
+    unsigned long long *counters; // {extension, shadow, paths} or nullptr
+};
+
+constexpr int MESH_REC_F4 = 12;
+constexpr float T_FAR = 1e30f;
+
+struct RayO { // RayOptimized, intersection.cuh:39-88
+    f3 o, d, inv;
+    bool sx, sy, sz;
+};
+PT_DEV RayO make_ray(f3 o, f3 d) {
+    RayO r;
+    r.o = o;
+    r.d = d;
+    r.inv.x = (__builtin_fabsf(d.x) > 1e-8f) ? (1.0f / d.x) : ((d.x >= 0) ? 1e30f : -1e30f);
+    r.inv.y = (__builtin_fabsf(d.y) > 1e-8f) ? (1.0f / d.y) : ((d.y >= 0) ? 1e30f : -1e30f);
+    r.inv.z = (__builtin_fabsf(d.z) > 1e-8f) ? (1.0f / d.z) : ((d.z >= 0) ? 1e30f : -1e30f);
+    r.sx = r.inv.x < 0;
+    r.sy = r.inv.y < 0;
+    r.sz = r.inv.z < 0;
+    return r;
+}
+
+// aabb_hit_fast / aabb_hit_fast_t (intersection.cuh:136-216) in one branch-free form (E2).
+// Hardware min/max are safe here: operands are never NaN and the sign of a zero
+// only ever feeds comparisons.
+PT_DEV bool slab(f3 bmin, f3 bmax, const RayO &r, float tMax, float &tEntry) {
+    const float ax = (bmin.x - r.o.x) * r.inv.x, bx = (bmax.x - r.o.x) * r.inv.x;
+    const float ay = (bmin.y - r.o.y) * r.inv.y, by = (bmax.y - r.o.y) * r.inv.y;
+    const float az = (bmin.z - r.o.z) * r.inv.z, bz = (bmax.z - r.o.z) * r.inv.z;
+    const float t0x = r.sx ? bx : ax, t1x = r.sx ? ax : bx;
+    const float t0y = r.sy ? by : ay, t1y = r.sy ? ay : by;
+    const float t0z = r.sz ? bz : az, t1z = r.sz ? az : bz;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(t0x, t0y), t0z);
+    const float tmax = __builtin_fminf(__builtin_fminf(t1x, t1y), t1z);
+    tEntry = __builtin_fmaxf(tmin, 0.0f);
+    return (tmax >= 0.0f) && (tmin <= tmax) && (tmin < tMax);
+}
+
+// triangle_intersect_fast (intersection.cuh:219-255) on a pre-differenced packet, plus
+// the caller's `t > 1e-5f` acceptance (intersection.cuh:329,379), branch-free.
+PT_DEV bool tri_test(f3 v0, f3 e1, f3 e2, const RayO &r, float tMax, float &t_out, float &u_out, float &v_out) {
+    const f3 h = cross(r.d, e2);
+    const float a = dot(e1, h);
+    const float f = 1.0f / a;
+    const f3 s = r.o - v0;
+    const float u = f * dot(s, h);
+    const f3 q = cross(s, e1);
+    const float v = f * dot(r.d, q);
+    const float t = f * dot(e2, q);
+    const bool ok = !(__builtin_fabsf(a) < 1e-6f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
+                    (t > 1e-6f && t < tMax) && (t > 1e-5f);
+    t_out = t;
+    u_out = u;
+    v_out = v;
+    return ok;
+}
+
+PT_DEV f3 xform_point(const float4 r0, const float4 r1, const float4 r2, f3 p) { // intersection.cuh:258-263
+    return mk3(r0.x * p.x + r0.y * p.y + r0.z * p.z + r0.w, r1.x * p.x + r1.y * p.y + r1.z * p.z + r1.w,
+               r2.x * p.x + r2.y * p.y + r2.z * p.z + r2.w);
+}
+PT_DEV f3 xform_dir(const float4 r0, const float4 r1, const float4 r2, f3 d) { // intersection.cuh:266-271
+    return mk3(r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z,
+               r2.x * d.x + r2.y * d.y + r2.z * d.z);
+}
+
+struct Hit {
+    float t;       // world-space distance (T_FAR = miss)
+    float t_local; // distance along the mesh-local ray (== t for untransformed meshes)
+    float u, v;
+    int mesh; // -1 = miss
+    int slot; // global leaf slot of the triangle
+};
+
+// LDS traversal stack of one wave: [entry][lane] of {ref, entry distance}
+struct LdsStack {
+    uint2 *base; // + lane
+    PT_DEV void push(int sp, int ref, float t) { base[sp * 64] = make_uint2((uint32_t)ref, __float_as_uint(t)); }
+    PT_DEV void pop(int sp, int &ref, float &t) {
+        const uint2 e = base[sp * 64];
+        ref = (int)e.x;
+        t = __uint_as_float(e.y);
+    }
+};
+
+// Closest hit inside one mesh's BLAS, local space (bvh_trace_local, intersection.cuh:344-435).
+// `ref` is the root reference (>=0 inner node, <0 ~leaf); the root box was already
+// tested by the caller.  Updates (tbest,u,v,slot) with strict `<`.
+template <bool UNIFORM_LEAF>
+PT_DEV void blas_closest(const KParams &K, int root_ref, bool alive, const RayO &r, LdsStack stk, float &tbest,
+                         float &ub, float &vb, int &slotb) {
+    if (UNIFORM_LEAF) {
+        // root is a leaf and the reference to it is wave-uniform: triangle packets come
+        // through scalar loads, every lane tests the same triangle
+        const int leaf = __builtin_amdgcn_readfirstlane(~root_ref);
+        const int2 lf = K.leaves[leaf];
+        for (int i = 0; i < lf.y; ++i) {
+            const int slot = lf.x + i;
+            const float4 p0 = K.tris[slot * 3 + 0], p1 = K.tris[slot * 3 + 1], p2 = K.tris[slot * 3 + 2];
+            float t, u, v;
+            const bool ok = tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, tbest, t, u, v);
+            if (alive && ok) {
+                tbest = t;
+                ub = u;
+                vb = v;
+                slotb = slot;
+            }
+        }
+        return;
+    }
+    int cur = root_ref;
+    int sp = 0;
+    bool active = alive;
+    while (active) {
+        if (cur >= 0) {
+            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
+                         n3 = K.nodes[cur * 4 + 3];
+            float tL, tR;
+            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), r, tbest, tL);
+            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), r, tbest, tR);
+            const int L = __float_as_int(n3.x), R = __float_as_int(n3.y);
+            if (hL || hR) {
+                const bool nearL = hL && (!hR || tL <= tR);
+                const int nearRef = nearL ? L : R;
+                const int farRef = nearL ? R : L;
+                const bool hitFar = nearL ? hR : hL;
+                if (hitFar) {
+                    stk.push(sp, farRef, nearL ? tR : tL);
+                    ++sp;
+                }
+                cur = nearRef;
+                continue;
+            }
+        } else {
+            const int2 lf = K.leaves[~cur];
+            for (int i = 0; i < lf.y; ++i) {
+                const int slot = lf.x + i;
+                const float4 p0 = K.tris[slot * 3 + 0], p1 = K.tris[slot * 3 + 1], p2 = K.tris[slot * 3 + 2];
+                float t, u, v;
+                if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, tbest, t, u, v)) {
+                    tbest = t;
+                    ub = u;
+                    vb = v;
+                    slotb = slot;
+                }
+            }
+        }
+        // pop the next subtree that can still contain a closer hit (E1)
+        active = false;
+        while (sp > 0) {
+            --sp;
+            int ref;
+            float tE;
+            stk.pop(sp, ref, tE);
+            if (tE < tbest) {
+                cur = ref;
+                active = true;
+                break;
+            }
+        }
+    }
+}
+
+// Any hit inside one mesh's BLAS (bvh_any_hit_local, intersection.cuh:300-341), E4.
+template <bool UNIFORM_LEAF>
+PT_DEV bool blas_any(const KParams &K, int root_ref, bool alive, const RayO &r, float tMax, LdsStack stk) {
+    bool found = false;
+    if (UNIFORM_LEAF) {
+        const int leaf = __builtin_amdgcn_readfirstlane(~root_ref);
+        const int2 lf = K.leaves[leaf];
+        for (int i = 0; i < lf.y; ++i) {
+            const int slot = lf.x + i;
+            const float4 p0 = K.tris[slot * 3 + 0], p1 = K.tris[slot * 3 + 1], p2 = K.tris[slot * 3 + 2];
+            float t, u, v;
+            found |= tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, tMax, t, u, v);
+        }
+        return alive && found;
+    }
+    int cur = root_ref;
+    int sp = 0;
+    bool active = alive;
+    while (active) {
+        if (cur >= 0) {
+            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
+                         n3 = K.nodes[cur * 4 + 3];
+            float tL, tR;
+            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), r, tMax, tL);
+            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), r, tMax, tR);
+            const int L = __float_as_int(n3.x), R = __float_as_int(n3.y);
+            if (hL && hR) {
+                stk.push(sp, R, 0.0f);
+                ++sp;
+                cur = L;
+                continue;
+            }
+            if (hL || hR) {
+                cur = hL ? L : R;
+                continue;
+            }
+        } else {
+            const int2 lf = K.leaves[~cur];
+            for (int i = 0; i < lf.y; ++i) {
+                const int slot = lf.x + i;
+                const float4 p0 = K.tris[slot * 3 + 0], p1 = K.tris[slot * 3 + 1], p2 = K.tris[slot * 3 + 2];
+                float t, u, v;
+                found |= tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, tMax, t, u, v);
+            }
+            if (found)
+                break;
+        }
+        active = false;
+        if (sp > 0) {
+            --sp;
+            float tE;
+            stk.pop(sp, cur, tE);
+            active = true;
+        }
+    }
+    return found;
+}
+
+struct MeshHead {
+    f3 bmin, bmax;
+    int root_ref, flags; // flags bit0 has_transform, bit1 skipped by shadow rays (transmission > 0.5)
+};
+PT_DEV MeshHead load_mesh_head(const KParams &K, int m) {
+    const float4 a = K.mesh_recs[m * MESH_REC_F4 + 0], b = K.mesh_recs[m * MESH_REC_F4 + 1];
+    MeshHead h;
+    h.bmin = mk3(a.x, a.y, a.z);
+    h.root_ref = __float_as_int(a.w);
+    h.bmax = mk3(b.x, b.y, b.z);
+    h.flags = __float_as_int(b.w);
+    return h;
+}
+// local-space ray of a transformed instance (transformRayToLocal, intersection.cuh:284-297)
+PT_DEV RayO local_ray(const KParams &K, int m, const RayO &w, float &dirScale) {
+    const float4 i0 = K.mesh_recs[m * MESH_REC_F4 + 2], i1 = K.mesh_recs[m * MESH_REC_F4 + 3],
+                 i2 = K.mesh_recs[m * MESH_REC_F4 + 4];
+    const f3 lo = xform_point(i0, i1, i2, w.o);
+    const f3 ld = xform_dir(i0, i1, i2, w.d);
+    dirScale = length(ld);
+    return make_ray(lo, normalize(ld));
+}
+
+// One mesh of a TLAS leaf, closest hit (bvh_trace + the merge in traceRay,
+// intersection.cuh:454-479,556-565).  GEOM 0: every BLAS is a single leaf.
+template <int GEOM, bool UNIFORM>
+PT_DEV void mesh_closest(const KParams &K, int m, bool alive, const RayO &w, LdsStack stk, Hit &best) {
+    if (UNIFORM)
+        m = __builtin_amdgcn_readfirstlane(m);
+    const MeshHead mh = load_mesh_head(K, m);
+    if (!(mh.flags & 1)) {
+        float tE;
+        const bool hb = alive && slab(mh.bmin, mh.bmax, w, T_FAR, tE);
+        if (UNIFORM && !__builtin_amdgcn_ballot_w64(hb))
+            return;
+        if (GEOM == 0 || (UNIFORM && mh.root_ref < 0)) {
+            // E3: a single-leaf BLAS has no inner boxes, so its triangles can run
+            // straight on the global best
+            float tb = best.t, ub = best.u, vb = best.v;
+            int sb = -1;
+            blas_closest<UNIFORM>(K, mh.root_ref, hb, w, stk, tb, ub, vb, sb);
+            if (sb >= 0) {
+                best.t = tb;
+                best.t_local = tb;
+                best.u = ub;
+                best.v = vb;
+                best.slot = sb;
+                best.mesh = m;
+            }
+            return;
+        }
+        // inner boxes must be culled against THIS mesh's best only (the reference
+        // restarts at 1e30 per mesh and its slab test is not conservative w.r.t. the
+        // triangle test), then merged with strict `<`
+        float tb = T_FAR, ub = 0.0f, vb = 0.0f;
+        int sb = -1;
+        blas_closest<false>(K, mh.root_ref, hb, w, stk, tb, ub, vb, sb);
+        if (sb >= 0 && tb < best.t) {
+            best.t = tb;
+            best.t_local = tb;
+            best.u = ub;
+            best.v = vb;
+            best.slot = sb;
+            best.mesh = m;
+        }
+        return;
+    }
+    float dirScale;
+    const RayO lr = local_ray(K, m, w, dirScale);
+    float tE;
+    const bool hb = alive && slab(mh.bmin, mh.bmax, lr, T_FAR, tE);
+    if (UNIFORM && !__builtin_amdgcn_ballot_w64(hb))
+        return;
+    float tb = T_FAR, ub = 0.0f, vb = 0.0f;
+    int sb = -1;
+    if (GEOM == 0 || (UNIFORM && mh.root_ref < 0))
+        blas_closest<UNIFORM>(K, mh.root_ref, hb, lr, stk, tb, ub, vb, sb);
+    else
+        blas_closest<false>(K, mh.root_ref, hb, lr, stk, tb, ub, vb, sb);
+    if (sb >= 0) {
+        const float tw = tb / dirScale;
+        if (tw < best.t) {
+            best.t = tw;
+            best.t_local = tb;
+            best.u = ub;
+            best.v = vb;
+            best.slot = sb;
+            best.mesh = m;
+        }
+    }
+}
+
+template <int GEOM, bool UNIFORM>
+PT_DEV bool mesh_any(const KParams &K, int m, bool alive, const RayO &w, float tMax, LdsStack stk) {
+    if (UNIFORM)
+        m = __builtin_amdgcn_readfirstlane(m);
+    const MeshHead mh = load_mesh_head(K, m);
+    if (mh.flags & 2) // transmission > 0.5: invisible to shadow rays (intersection.cuh:509-511)
+        return false;
+    RayO r = w;
+    float tm = tMax;
+    if (mh.flags & 1) {
+        float dirScale;
+        r = local_ray(K, m, w, dirScale);
+        tm = tMax * dirScale;
+    }
+    float tE;
+    const bool hb = alive && slab(mh.bmin, mh.bmax, r, tm, tE);
+    if (UNIFORM && !__builtin_amdgcn_ballot_w64(hb))
+        return false;
+    if (GEOM == 0 || (UNIFORM && mh.root_ref < 0))
+        return blas_any<UNIFORM>(K, mh.root_ref, hb, r, tm, stk);
+    return blas_any<false>(K, mh.root_ref, hb, r, tm, stk);
+}
+
+// traceRay (intersection.cuh:526-605).  GEOM 0/1: the TLAS is a single leaf, so the
+// mesh loop is wave-uniform.  GEOM 2: general TLAS with a small private stack.
+template <int GEOM> PT_DEV Hit closest_hit(const KParams &K, bool alive, f3 o, f3 d, LdsStack stk) {
+    Hit best;
+    best.t = T_FAR;
+    best.t_local = T_FAR;
+    best.u = best.v = 0.0f;
+    best.mesh = -1;
+    best.slot = -1;
+    const RayO w = make_ray(o, d);
+    float tE;
+    alive = alive && slab(mk3(K.tlas_root_min[0], K.tlas_root_min[1], K.tlas_root_min[2]),
+                          mk3(K.tlas_root_max[0], K.tlas_root_max[1], K.tlas_root_max[2]), w, T_FAR, tE);
+    if (GEOM < 2) {
+        const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+        for (int i = 0; i < lf.y; ++i)
+            mesh_closest<GEOM, true>(K, K.tlas_mesh_ids[lf.x + i], alive, w, stk, best);
+        return best;
+    }
+    int tstack_ref[24];
+    float tstack_t[24];
+    int sp = 0;
+    int cur = K.tlas_root_ref;
+    bool active = alive;
+    while (active) {
+        if (cur >= 0) {
+            const float4 n0 = K.tlas_nodes[cur * 4 + 0], n1 = K.tlas_nodes[cur * 4 + 1], n2 = K.tlas_nodes[cur * 4 + 2],
+                         n3 = K.tlas_nodes[cur * 4 + 3];
+            float tL, tR;
+            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, best.t, tL);
+            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, best.t, tR);
+            const int L = __float_as_int(n3.x), R = __float_as_int(n3.y);
+            if (hL || hR) {
+                const bool nearL = hL && (!hR || tL <= tR);
+                if (nearL ? hR : hL) {
+                    tstack_ref[sp] = nearL ? R : L;
+                    tstack_t[sp] = nearL ? tR : tL;
+                    ++sp;
+                }
+                cur = nearL ? L : R;
+                continue;
+            }
+        } else {
+            const int2 lf = K.tlas_leaves[~cur];
+            for (int i = 0; i < lf.y; ++i)
+                mesh_closest<GEOM, false>(K, K.tlas_mesh_ids[lf.x + i], true, w, stk, best);
+        }
+        active = false;
+        while (sp > 0) {
+            --sp;
+            if (tstack_t[sp] < best.t) {
+                cur = tstack_ref[sp];
+                active = true;
+                break;
+            }
+        }
+    }
+    return best;
+}
+
+// bvh_any_hit_tlas (intersection.cuh:481-524)
+template <int GEOM> PT_DEV bool any_hit(const KParams &K, bool alive, f3 o, f3 d, float tMax, LdsStack stk) {
+    const RayO w = make_ray(o, d);
+    float tE;
+    alive = alive && slab(mk3(K.tlas_root_min[0], K.tlas_root_min[1], K.tlas_root_min[2]),
+                          mk3(K.tlas_root_max[0], K.tlas_root_max[1], K.tlas_root_max[2]), w, tMax, tE);
+    bool found = false;
+    if (GEOM < 2) {
+        const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+        for (int i = 0; i < lf.y; ++i) {
+            found |= mesh_any<GEOM, true>(K, K.tlas_mesh_ids[lf.x + i], alive && !found, w, tMax, stk);
+            if (!__builtin_amdgcn_ballot_w64(alive && !found))
+                break;
+        }
+        return found;
+    }
+    int tstack_ref[24];
+    int sp = 0;
+    int cur = K.tlas_root_ref;
+    bool active = alive;
+    while (active) {
+        if (cur >= 0) {
+            const float4 n0 = K.tlas_nodes[cur * 4 + 0], n1 = K.tlas_nodes[cur * 4 + 1], n2 = K.tlas_nodes[cur * 4 + 2],
+                         n3 = K.tlas_nodes[cur * 4 + 3];
+            float tL, tR;
+            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, tMax, tL);
+            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, tMax, tR);
+            const int L = __float_as_int(n3.x), R = __float_as_int(n3.y);
+            if (hL && hR) {
+                tstack_ref[sp++] = R;
+                cur = L;
+                continue;
+            }
+            if (hL || hR) {
+                cur = hL ? L : R;
+                continue;
+            }
+        } else {
+            const int2 lf = K.tlas_leaves[~cur];
+            for (int i = 0; i < lf.y && !found; ++i)
+                found |= mesh_any<GEOM, false>(K, K.tlas_mesh_ids[lf.x + i], true, w, tMax, stk);
+            if (found)
+                break;
+        }
+        active = false;
+        if (sp > 0) {
+            cur = tstack_ref[--sp];
+            active = true;
+        }
+    }
+    return found;
+}
+
+// HitInfo fields derived from the winning triangle (intersection.cuh:380-392,465-476)
+PT_DEV Surface make_surface(const KParams &K, const Hit &h, f3 o, f3 d, f3 *local_point, int *face_index) {
+    const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
+    const f3 e1 = mk3(p1.x, p1.y, p1.z), e2 = mk3(p2.x, p2.y, p2.z);
+    const f3 gn = normalize(cross(e1, e2));
+    const int flags = __float_as_int(K.mesh_recs[h.mesh * MESH_REC_F4 + 1].w);
+    Surface s;
+    s.t = h.t;
+    if (face_index)
+        *face_index = __float_as_int(p0.w);
+    if (!(flags & 1)) {
+        s.point = o + h.t * d;
+        s.front_face = dot(d, gn) < 0.0f;
+        s.normal = s.front_face ? gn : -gn;
+        if (local_point)
+            *local_point = s.point;
+        return s;
+    }
+    const float4 *rec = K.mesh_recs + h.mesh * MESH_REC_F4;
+    const f3 lo = xform_point(rec[2], rec[3], rec[4], o);
+    const f3 ld = normalize(xform_dir(rec[2], rec[3], rec[4], d));
+    const f3 lp = lo + h.t_local * ld;
+    const bool lfront = dot(ld, gn) < 0.0f;
+    const f3 ln = lfront ? gn : -gn;
+    s.point = xform_point(rec[5], rec[6], rec[7], lp);
+    const f3 wn = normalize(xform_dir(rec[8], rec[9], rec[10], ln));
+    s.front_face = dot(d, wn) < 0.0f;
+    s.normal = s.front_face ? wn : -wn;
+    if (local_point)
+        *local_point = lp;
+    return s;
+}
+
+struct LightRec {
+    f3 position, direction, color;
+    int type;
+    float intensity, range, inner, outer, radius;
+};
+PT_DEV LightRec load_light(const float4 *__restrict__ L, int i) {
+    const float4 a = L[i * 4 + 0], b = L[i * 4 + 1], c = L[i * 4 + 2], d = L[i * 4 + 3];
+    LightRec l;
+    l.position = mk3(a.x, a.y, a.z);
+    l.type = __float_as_int(a.w);
+    l.direction = mk3(b.x, b.y, b.z);
+    l.intensity = b.w;
+    l.color = mk3(c.x, c.y, c.z);
+    l.range = c.w;
+    l.inner = d.x;
+    l.outer = d.y;
+    l.radius = d.z;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------
+// the render loop
+// ---------------------------------------------------------------------------------
+template <int GEOM, bool FULL> __global__ __launch_bounds__(64) void path_trace_kernel(const KParams K) {
+    extern __shared__ uint2 lds_stack[];
+    const int lane = threadIdx.x;
+    LdsStack stk{lds_stack + lane};
+    const int tile = blockIdx.x;
+    const int tx = tile % K.tiles_x, ty = tile / K.tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int yl = ty * 8 + (lane >> 3);
+    const bool inside = (x < K.width) && (yl < K.rows);
+    const int y = K.y0 + yl;
+    const size_t npix = (size_t)K.rows * K.width;
+    const size_t idx = (size_t)yl * K.width + x;
+
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    if (inside) {
+        rng.d = K.rng[idx];
+        rng.v0 = K.rng[npix + idx];
+        rng.v1 = K.rng[2 * npix + idx];
+        rng.v2 = K.rng[3 * npix + idx];
+        rng.v3 = K.rng[4 * npix + idx];
+        rng.v4 = K.rng[5 * npix + idx];
+    }
+
+    f3 avg_color = mk3(0.0f);
+    f3 first_normal = mk3(0.0f);
+    float first_depth = 1e30f;
+    int first_id = -1;
+    uint32_t n_ext = 0, n_shadow = 0;
+
+    int s = inside ? 0 : K.spp;
+    int bounce = 0;
+    bool fresh = true;
+    f3 ro = mk3(0.0f), rd = mk3(0.0f);
+    bool ray_spec = true, prev_was_specular = true;
+    f3 throughput = mk3(1.0f), acc = mk3(0.0f);
+
+    while (__builtin_amdgcn_ballot_w64(s < K.spp)) {
+        const bool live = s < K.spp;
+        if (live && fresh) {
+            // primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
+            float tjx, tjy, bnx, bny;
+            taa_jitter(K.frame_count + s, tjx, tjy);
+            blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);
+            const float jitter_x = tjx + (bnx - 0.5f) * 0.25f;
+            const float jitter_y = tjy + (bny - 0.5f) * 0.25f;
+            const float u = ((float)x + 0.5f + jitter_x) / (float)K.width;
+            const float v = 1.0f - ((float)y + 0.5f + jitter_y) / (float)K.height;
+            if (K.cam.lens_radius <= 0) {
+                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin;
+                ro = K.cam.origin;
+                rd = normalize(dir);
+            } else {
+                f3 p;
+                do {
+                    const float a = rng_uniform(rng);
+                    const float b = rng_uniform(rng);
+                    p = 2.0f * mk3(a, b, 0.0f) - mk3(1.0f, 1.0f, 0.0f);
+                } while (dot(p, p) >= 1.0f);
+                const f3 rdisk = K.cam.lens_radius * p;
+                const f3 offset = K.cam.u * rdisk.x + K.cam.v * rdisk.y;
+                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin - offset;
+                ro = K.cam.origin + offset;
+                rd = normalize(dir);
+            }
+            ray_spec = true;
+            prev_was_specular = true;
+            throughput = mk3(1.0f);
+            acc = mk3(0.0f);
+            bounce = 0;
+            fresh = false;
+        }
+
+        const Hit h = closest_hit<GEOM>(K, live, ro, rd, stk);
+        if (live) {
+            ++n_ext;
+            bool end_path = false;
+            if (h.mesh < 0) {
+                if (bounce == 0 && s == 0) {
+                    first_normal = mk3(0.0f);
+                    first_depth = 1e30f;
+                    first_id = -1;
+                }
+                if (K.use_sky) { // sampleSky, gradient (render_utils.cuh:115-125)
+                    const float t = 0.5f * (rd.y + 1.0f);
+                    acc = acc + throughput * lerp(K.sky_bottom, K.sky_top, t);
+                } else {
+                    acc = acc + throughput * mk3(0.0f);
+                }
+                end_path = true;
+            } else {
+                const Surface hit = make_surface(K, h, ro, rd, nullptr, nullptr);
+                if (bounce == 0 && s == 0) {
+                    first_normal = hit.normal;
+                    first_depth = hit.t;
+                    first_id = h.mesh;
+                }
+                const Material mat = load_material(K.materials, h.mesh);
+                const f3 V = -rd;
+                if (!hit.front_face) { // Beer-Lambert on back faces (path_logic.cuh:823-829)
+                    const f3 T_unit = mk3(max_(1e-6f, mat.albedo.x), max_(1e-6f, mat.albedo.y), max_(1e-6f, mat.albedo.z));
+                    const f3 absorption = mk3(-det_log(T_unit.x), -det_log(T_unit.y), -det_log(T_unit.z));
+                    throughput = throughput * beerLambert(absorption, hit.t);
+                }
+                if (mat.emission.x > 0.0f || mat.emission.y > 0.0f || mat.emission.z > 0.0f) {
+                    if (bounce == 0 || prev_was_specular)
+                        acc = acc + throughput * mat.emission;
+                }
+                // next-event estimation (path_logic.cuh:305-393, 840-857)
+                if (!ray_spec && K.n_lights > 0) {
+                    float r = rng_uniform(rng);
+                    r = min_(r, 0.99999994f);
+                    const int light_index = (int)(r * (float)K.n_lights);
+                    const LightRec light = load_light(K.lights, light_index);
+                    const float pdf_pick = 1.0f / (float)K.n_lights;
+                    f3 L;
+                    float attenuation = 1.0f;
+                    float light_dist = 1e30f;
+                    const f3 light_radiance = light.color * light.intensity;
+                    float pdf_sample = 1.0f;
+                    if (light.type == 1) {
+                        L = -light.direction;
+                        pdf_sample = pdf_pick;
+                    } else {
+                        const f3 toLight = light.position - hit.point;
+                        const float light_dist_sq = dot(toLight, toLight);
+                        light_dist = __builtin_sqrtf(light_dist_sq);
+                        if (light.radius <= 0.0f) {
+                            L = toLight / light_dist;
+                            pdf_sample = pdf_pick;
+                        } else {
+                            float sin_theta_max_sq = (light.radius * light.radius) / light_dist_sq;
+                            sin_theta_max_sq = min_(sin_theta_max_sq, 0.9999f);
+                            const float cos_theta_max = __builtin_sqrtf(1.0f - sin_theta_max_sq);
+                            L = sample_cone_direction(rng, toLight / light_dist, cos_theta_max);
+                            const float solid_angle = TWO_PI_F * (1.0f - cos_theta_max);
+                            pdf_sample = (solid_angle > 1e-6f) ? (pdf_pick / solid_angle) : pdf_pick;
+                        }
+                        attenuation = attenuate(light_dist, light.range);
+                        if (light.type == 2) {
+                            const float theta = dot(L, -light.direction);
+                            const float epsilon = light.inner - light.outer;
+                            float spotIntensity;
+                            if (epsilon <= 1e-6f)
+                                spotIntensity = (theta >= light.outer) ? 1.0f : 0.0f;
+                            else
+                                spotIntensity = clampf((theta - light.outer) / epsilon, 0.0f, 1.0f);
+                            attenuation *= spotIntensity;
+                        }
+                    }
+                    const f3 shadow_offset = dot(hit.normal, L) > 0.0f ? hit.normal * 1e-4f : -hit.normal * 1e-4f;
+                    ++n_shadow;
+                    const bool inShadow = any_hit<GEOM>(K, true, hit.point + shadow_offset, L, light_dist - 1e-3f, stk);
+                    if (!inShadow) {
+                        const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
+                        if (pdf_sample > 0.0f) {
+                            f3 direct = bsdf * light_radiance * attenuation / pdf_sample;
+                            direct = clamp_vector_soft(direct, 500.0f);
+                            if (direct.x > 0.0f || direct.y > 0.0f || direct.z > 0.0f) {
+                                const float pdf_brdf = material_pdf<FULL>(hit, mat, V, L);
+                                const float wgt = mis_weight(pdf_sample, pdf_brdf);
+                                acc = acc + throughput * direct * wgt;
+                            }
+                        }
+                    }
+                }
+                f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
+                bool is_specular = false;
+                if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular)) {
+                    end_path = true;
+                } else {
+                    prev_was_specular = is_specular;
+                    bool killed = false;
+                    if (bounce >= 2) { // Russian roulette (path_logic.cuh:871-880)
+                        const float p = max_(0.05f, min_(0.95f, max_(throughput.x, max_(throughput.y, throughput.z))));
+                        if (rng_uniform(rng) > p)
+                            killed = true;
+                        else
+                            throughput = throughput / p;
+                    }
+                    if (killed) {
+                        end_path = true;
+                    } else {
+                        throughput = throughput * att;
+                        throughput = clamp_vector_soft(throughput, 50.0f);
+                        const f3 off = hit.normal * 1e-4f;
+                        ro = (dot(scatter_dir, hit.normal) > 0.0f) ? (hit.point + off) : (hit.point - off);
+                        rd = scatter_dir;
+                        ray_spec = is_specular;
+                        ++bounce;
+                        if (bounce >= K.max_depth)
+                            end_path = true;
+                    }
+                }
+            }
+            if (end_path) {
+                acc = clamp_vector_soft(acc, 100.0f);
+                avg_color = avg_color + acc;
+                ++s;
+                fresh = true;
+            }
+        }
+    }
+
+    if (inside) {
+        K.rng[idx] = rng.d;
+        K.rng[npix + idx] = rng.v0;
+        K.rng[2 * npix + idx] = rng.v1;
+        K.rng[3 * npix + idx] = rng.v2;
+        K.rng[4 * npix + idx] = rng.v3;
+        K.rng[5 * npix + idx] = rng.v4;
+        const f3 out = avg_color / (float)K.spp;
+        K.accum[idx * 3 + 0] = out.x;
+        K.accum[idx * 3 + 1] = out.y;
+        K.accum[idx * 3 + 2] = out.z;
+        K.normal[idx * 3 + 0] = first_normal.x;
+        K.normal[idx * 3 + 1] = first_normal.y;
+        K.normal[idx * 3 + 2] = first_normal.z;
+        K.depth[idx] = first_depth;
+        K.object_id[idx] = first_id;
+        // tonemap_kernel fused: RGB8, rows flipped within the tile (scene.cuh:2013-2015)
+        unsigned char r8, g8, b8;
+        tonemap_pixel(out, r8, g8, b8);
+        const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
+        K.rgb8[o + 0] = r8;
+        K.rgb8[o + 1] = g8;
+        K.rgb8[o + 2] = b8;
+    }
+    if (K.counters) {
+        uint32_t a = n_ext, b = n_shadow, c = inside ? (uint32_t)K.spp : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
+            c += __shfl_xor(c, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&K.counters[0], (unsigned long long)a);
+            atomicAdd(&K.counters[1], (unsigned long long)b);
+            atomicAdd(&K.counters[2], (unsigned long long)c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// XORWOW initialisation: state(seed) advanced by `global pixel index` subsequences of
+// 2^67 draws.  jump[k] = (step^(2^67))^(2^k) as 160 columns x 5 words; a lane applies
+// the matrices selected by the bits of its pixel index.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xorwow_init_kernel(uint32_t *rng, int width, int rows, int y0, uint32_t d0,
+                                                          uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
+                                                          uint32_t s4, const uint32_t *__restrict__ jump, int n_jump) {
+    const size_t npix = (size_t)rows * width;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix)
+        return;
+    unsigned long long n = (unsigned long long)y0 * (unsigned long long)width + i; // global y*W+x
+    uint32_t v[5] = {s0, s1, s2, s3, s4};
+    for (int k = 0; k < n_jump && n; ++k, n >>= 1) {
+        if (!(n & 1ull))
+            continue;
+        const uint32_t *M = jump + (size_t)k * 800;
+        uint32_t a[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < 5; ++w) {
+            uint32_t bits = v[w];
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const uint32_t *c = M + (w * 32 + b) * 5;
+                a[0] ^= c[0];
+                a[1] ^= c[1];
+                a[2] ^= c[2];
+                a[3] ^= c[3];
+                a[4] ^= c[4];
+            }
+        }
+        for (int w = 0; w < 5; ++w)
+            v[w] = a[w];
+    }
+    rng[i] = d0;
+    rng[npix + i] = v[0];
+    rng[2 * npix + i] = v[1];
+    rng[3 * npix + i] = v[2];
+    rng[4 * npix + i] = v[3];
+    rng[5 * npix + i] = v[4];
+}
+
+// canonical {d,v0..v4}-per-pixel order <-> the private planar layout
+__global__ void rng_planar_to_aos(const uint32_t *planar, uint32_t *aos, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix)
+        return;
+    for (int k = 0; k < 6; ++k)
+        aos[i * 6 + k] = planar[(size_t)k * npix + i];
+}
+__global__ void rng_aos_to_planar(const uint32_t *aos, uint32_t *planar, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix)
+        return;
+    for (int k = 0; k < 6; ++k)
+        planar[(size_t)k * npix + i] = aos[i * 6 + k];
+}
+
+// ---------------------------------------------------------------------------------
+// trace_single_ray_kernel, batched: one lane per ray
+// ---------------------------------------------------------------------------------
+struct HitOut { // == ptrt_hit (include/ptrt.h)
+    int hit;
+    float t;
+    float point[3], normal[3];
+    int mesh_index, front_face;
+    float u, v;
+    int face_index;
+    float local_point[3];
+};
+template <int GEOM>
+__global__ __launch_bounds__(64) void trace_rays_kernel(const KParams K, const float *origins, const float *dirs, int n,
+                                                        HitOut *out) {
+    extern __shared__ uint2 lds_stack[];
+    LdsStack stk{lds_stack + threadIdx.x};
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const bool live = i < n;
+    const int j = live ? i : 0;
+    const f3 o = mk3(origins[j * 3], origins[j * 3 + 1], origins[j * 3 + 2]);
+    const f3 d = mk3(dirs[j * 3], dirs[j * 3 + 1], dirs[j * 3 + 2]);
+    const Hit h = closest_hit<GEOM>(K, live, o, d, stk);
+    if (!live)
+        return;
+    HitOut r;
+    if (h.mesh < 0) { // HitInfo() defaults (intersection.cuh:122-124)
+        r.hit = 0;
+        r.t = 1e30f;
+        r.point[0] = r.point[1] = r.point[2] = 0.0f;
+        r.normal[0] = r.normal[1] = r.normal[2] = 0.0f;
+        r.mesh_index = -1;
+        r.front_face = 1;
+        r.u = r.v = 0.0f;
+        r.face_index = -1;
+        r.local_point[0] = r.local_point[1] = r.local_point[2] = 0.0f;
+    } else {
+        f3 lp;
+        int face;
+        const Surface s = make_surface(K, h, o, d, &lp, &face);
+        r.hit = 1;
+        r.t = h.t;
+        r.point[0] = s.point.x; r.point[1] = s.point.y; r.point[2] = s.point.z;
+        r.normal[0] = s.normal.x; r.normal[1] = s.normal.y; r.normal[2] = s.normal.z;
+        r.mesh_index = h.mesh;
+        r.front_face = s.front_face ? 1 : 0;
+        r.u = h.u;
+        r.v = h.v;
+        r.face_index = face;
+        r.local_point[0] = lp.x; r.local_point[1] = lp.y; r.local_point[2] = lp.z;
+    }
+    out[i] = r;
+}
+
+// deterministic-math probe for tests: op 0 sin, 1 cos, 2 exp, 3 log, 4 pow
+__global__ void detmath_kernel(int op, const float *x, const float *y, int n, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    float r;
+    switch (op) {
+    case 0: r = det_sin(x[i]); break;
+    case 1: r = det_cos(x[i]); break;
+    case 2: r = det_exp(x[i]); break;
+    case 3: r = det_log(x[i]); break;
+    default: r = det_pow(x[i], y[i]); break;
+    }
+    out[i] = r;
+}
+
+} // namespace pt

@@ -1,0 +1,943 @@
+// ptrt_capi.hip -- implementation of the C ABI in include/ptrt.h over HIP (gfx950).
+//
+// Host responsibilities here: own every device allocation of a context, re-lay-out
+// the caller's reference-shaped scene arrays (40-byte nodes, index triples,
+// per-mesh pointers; mesh.cuh:37-47, intersection.cuh:90-106) into the arena the
+// kernels read (pt_kernels.hip.h), pick the kernel instantiation that matches the
+// scene, launch on the context's stream, time kernels with HIP events.
+// There is no CPU rendering path in this library.
+#include "../../include/ptrt.h"
+#include "pt_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error = "";
+std::mutex g_live_mutex;
+std::set<ptrt_ctx *> g_live;
+
+} // namespace
+
+struct ptrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int W = 0, H = 0, y0 = 0, rows = 0;
+    size_t npix = 0;
+    std::string err;
+
+    // frame buffers (tile)
+    uint32_t *d_rng = nullptr;
+    float *d_accum = nullptr, *d_normal = nullptr, *d_depth = nullptr;
+    int *d_object_id = nullptr;
+    unsigned char *d_rgb8 = nullptr;
+    unsigned char *last_rgb8 = nullptr; // where the last frame's RGB8 went
+    unsigned long long *d_counters = nullptr;
+    float2 *d_blue = nullptr;
+    uint32_t *d_jump = nullptr;
+    int n_jump = 0;
+    bool rng_ready = false;
+
+    // scene arena
+    float4 *d_mesh_recs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_tlas_nodes = nullptr,
+           *d_materials = nullptr, *d_lights = nullptr;
+    int2 *d_leaves = nullptr, *d_tlas_leaves = nullptr;
+    int *d_tlas_mesh_ids = nullptr;
+    std::vector<float4> h_mesh_recs;
+    std::vector<unsigned char> h_shadow_skip; // per material: transmission > 0.5
+    int n_meshes = 0, n_materials = 0, n_lights = 0;
+    float tlas_root_min[3] = {0, 0, 0}, tlas_root_max[3] = {0, 0, 0};
+    int tlas_root_ref = 0;
+    bool tlas_single_leaf = false, all_single_leaf = false, mats_full = false;
+    int stack_entries = 1;
+    bool have_geometry = false, have_materials = false;
+
+    pt::Camera cam{};
+    pt::f3 sky_top{0.6f, 0.7f, 1.0f}, sky_bottom{1.0f, 1.0f, 1.0f};
+    int use_sky = 1;
+
+    // options
+    int count_rays = 0, force_geom = -1, force_full = 0;
+    bool timed = false;
+};
+
+namespace {
+
+int fail(ptrt_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (c)
+        c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                                       \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail((c), PTRT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                       \
+    } while (0)
+
+template <class T> void dfree(T *&p) {
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+}
+template <class T> int upload(ptrt_ctx *c, T *&dst, const std::vector<T> &src) {
+    dfree(dst);
+    const size_t n = src.empty() ? 1 : src.size();
+    HIP_TRY(c, hipMalloc((void **)&dst, n * sizeof(T)));
+    if (!src.empty())
+        HIP_TRY(c, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // src may be a temporary
+    return PTRT_OK;
+}
+
+float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+float as_f(int i) {
+    float f;
+    std::memcpy(&f, &i, 4);
+    return f;
+}
+
+// ---- GF(2) algebra for the XORWOW subsequence jump (cuRAND: subsequence = 2^67 draws) ----
+struct GF2 {
+    uint32_t col[160][5];
+};
+void gf2_apply(const GF2 &m, const uint32_t in[5], uint32_t out[5]) {
+    uint32_t a[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; ++w)
+        for (uint32_t bits = in[w]; bits; bits &= bits - 1) {
+            const uint32_t *c = m.col[w * 32 + __builtin_ctz(bits)];
+            for (int k = 0; k < 5; ++k)
+                a[k] ^= c[k];
+        }
+    std::memcpy(out, a, sizeof a);
+}
+void gf2_square(GF2 &m) {
+    GF2 t;
+    for (int j = 0; j < 160; ++j)
+        gf2_apply(m, m.col[j], t.col[j]);
+    m = t;
+}
+// jump[k] = (one generator step)^(2^(67+k)), k = 0..n-1, as 800 words each
+const std::vector<uint32_t> &jump_matrices(int n) {
+    static std::vector<uint32_t> out;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)out.size() >= n * 800)
+        return out;
+    GF2 m;
+    for (int j = 0; j < 160; ++j) { // image of basis vector j under one step of the recurrence
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        v[j / 32] = 1u << (j % 32);
+        const uint32_t t = v[0] ^ (v[0] >> 2);
+        uint32_t nv[5] = {v[1], v[2], v[3], v[4], (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1))};
+        std::memcpy(m.col[j], nv, sizeof nv);
+    }
+    for (int i = 0; i < 67; ++i)
+        gf2_square(m);
+    out.resize((size_t)n * 800);
+    for (int k = 0; k < n; ++k) {
+        std::memcpy(&out[(size_t)k * 800], m.col, 800 * sizeof(uint32_t));
+        gf2_square(m);
+    }
+    return out;
+}
+
+// ---- scene re-layout ---------------------------------------------------------------
+struct Relayout {
+    std::vector<float4> nodes; // child-pair inner nodes
+    std::vector<int2> leaves;
+    std::vector<float4> tris;
+    int max_depth = 0;
+};
+
+// Converts one reference-shaped tree (pre-order 40-byte nodes) into child-pair nodes.
+// `emit_leaf(start,count)` returns the leaf id for a leaf node.  Returns the root
+// reference, or INT32_MIN on malformed input.
+template <class EmitLeaf>
+int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nodes, EmitLeaf emit_leaf, int &max_depth,
+                 std::string &why) {
+    struct Item {
+        int old_idx, new_idx, depth;
+    };
+    if (n_in <= 0) {
+        why = "empty node array";
+        return INT32_MIN;
+    }
+    std::vector<char> seen((size_t)n_in, 0);
+    auto ref_of = [&](int old_idx, int depth, std::vector<Item> &work) -> int {
+        if (old_idx < 0)
+            return ~emit_leaf(0, 0); // absent child: an empty leaf behind an unhittable box
+        if (old_idx >= n_in) {
+            why = "child index out of range";
+            return INT32_MIN;
+        }
+        if (seen[old_idx]) {
+            why = "node referenced twice (not a tree)";
+            return INT32_MIN;
+        }
+        seen[old_idx] = 1;
+        const ptrt_bvh_node &N = in[old_idx];
+        if (N.count > 0)
+            return ~emit_leaf(N.start, N.count);
+        const int ni = (int)(out_nodes.size() / 4);
+        out_nodes.resize(out_nodes.size() + 4);
+        work.push_back({old_idx, ni, depth + 1});
+        return ni;
+    };
+    std::vector<Item> work;
+    const int root = ref_of(0, 0, work);
+    if (root == INT32_MIN)
+        return root;
+    while (!work.empty()) {
+        const Item it = work.back();
+        work.pop_back();
+        if (it.depth > max_depth)
+            max_depth = it.depth;
+        const ptrt_bvh_node &N = in[it.old_idx];
+        const int L = ref_of(N.left, it.depth, work);
+        if (L == INT32_MIN)
+            return L;
+        const int R = ref_of(N.right, it.depth, work);
+        if (R == INT32_MIN)
+            return R;
+        const float BIG = 1e30f;
+        ptrt_vec3 lmin{BIG, BIG, BIG}, lmax{-BIG, -BIG, -BIG}, rmin = lmin, rmax = lmax;
+        if (N.left >= 0) {
+            lmin = in[N.left].bmin;
+            lmax = in[N.left].bmax;
+        }
+        if (N.right >= 0) {
+            rmin = in[N.right].bmin;
+            rmax = in[N.right].bmax;
+        }
+        float4 *o = &out_nodes[(size_t)it.new_idx * 4];
+        o[0] = f4(lmin.x, lmin.y, lmin.z, lmax.x);
+        o[1] = f4(lmax.y, lmax.z, rmin.x, rmin.y);
+        o[2] = f4(rmin.z, rmax.x, rmax.y, rmax.z);
+        o[3] = f4(as_f(L), as_f(R), 0.0f, 0.0f);
+    }
+    return root;
+}
+
+void free_scene(ptrt_ctx *c) {
+    dfree(c->d_mesh_recs);
+    dfree(c->d_nodes);
+    dfree(c->d_tris);
+    dfree(c->d_tlas_nodes);
+    dfree(c->d_leaves);
+    dfree(c->d_tlas_leaves);
+    dfree(c->d_tlas_mesh_ids);
+}
+
+int push_mesh_recs(ptrt_ctx *c) {
+    // flags bit1 (skipped by shadow rays) comes from the materials; re-applied on either upload
+    std::vector<float4> recs = c->h_mesh_recs;
+    for (int m = 0; m < c->n_meshes; ++m) {
+        int flags;
+        std::memcpy(&flags, &recs[(size_t)m * pt::MESH_REC_F4 + 1].w, 4);
+        flags &= ~2;
+        if (m < (int)c->h_shadow_skip.size() && c->h_shadow_skip[m])
+            flags |= 2;
+        recs[(size_t)m * pt::MESH_REC_F4 + 1].w = as_f(flags);
+    }
+    return upload(c, c->d_mesh_recs, recs);
+}
+
+int set_device(ptrt_ctx *c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return PTRT_OK;
+}
+
+pt::KParams make_params(ptrt_ctx *c) {
+    pt::KParams K{};
+    K.mesh_recs = c->d_mesh_recs;
+    K.nodes = c->d_nodes;
+    K.leaves = c->d_leaves;
+    K.tris = c->d_tris;
+    K.tlas_nodes = c->d_tlas_nodes;
+    K.tlas_leaves = c->d_tlas_leaves;
+    K.tlas_mesh_ids = c->d_tlas_mesh_ids;
+    K.materials = c->d_materials;
+    K.lights = c->d_lights;
+    K.blue_noise = c->d_blue;
+    for (int k = 0; k < 3; ++k) {
+        K.tlas_root_min[k] = c->tlas_root_min[k];
+        K.tlas_root_max[k] = c->tlas_root_max[k];
+    }
+    K.tlas_root_ref = c->tlas_root_ref;
+    K.n_meshes = c->n_meshes;
+    K.n_lights = c->n_lights;
+    K.stack_entries = c->stack_entries;
+    K.cam = c->cam;
+    K.sky_top = c->sky_top;
+    K.sky_bottom = c->sky_bottom;
+    K.use_sky = c->use_sky;
+    K.width = c->W;
+    K.height = c->H;
+    K.y0 = c->y0;
+    K.rows = c->rows;
+    K.tiles_x = (c->W + 7) / 8;
+    K.rng = c->d_rng;
+    K.accum = c->d_accum;
+    K.normal = c->d_normal;
+    K.depth = c->d_depth;
+    K.object_id = c->d_object_id;
+    K.rgb8 = c->d_rgb8;
+    K.counters = nullptr;
+    return K;
+}
+
+int pick_geom(ptrt_ctx *c) {
+    int g = c->tlas_single_leaf ? (c->all_single_leaf ? 0 : 1) : 2;
+    if (c->force_geom > g)
+        g = c->force_geom; // a more general variant is always valid
+    return g;
+}
+
+template <int GEOM> void launch_trace(ptrt_ctx *c, const pt::KParams &K, bool full, int grid, size_t lds) {
+    if (full)
+        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true>), dim3(grid), dim3(64), lds, c->stream, K);
+    else
+        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false>), dim3(grid), dim3(64), lds, c->stream, K);
+}
+
+bool ctx_live(ptrt_ctx *c) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    return c && g_live.count(c);
+}
+
+} // namespace
+
+// =====================================================================================
+extern "C" {
+
+int ptrt_abi_version(void) { return PTRT_ABI_VERSION; }
+
+const char *ptrt_last_error(const ptrt_ctx *ctx) {
+    if (ctx && ctx_live(const_cast<ptrt_ctx *>(ctx)))
+        return ctx->err.c_str();
+    return g_last_error.c_str();
+}
+
+int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, ptrt_ctx **out) {
+    if (!out)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_create: out is NULL");
+    *out = nullptr;
+    if (full_w <= 0 || full_h <= 0)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_create: bad frame size %dx%d", full_w, full_h);
+    if (tile_rows <= 0) {
+        tile_y0 = 0;
+        tile_rows = full_h;
+    }
+    if (tile_y0 < 0 || tile_y0 + tile_rows > full_h)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_create: tile rows [%d,%d) outside 0..%d", tile_y0,
+                    tile_y0 + tile_rows, full_h);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PTRT_E_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, PTRT_E_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    ptrt_ctx *c = new ptrt_ctx();
+    c->device = device;
+    c->W = full_w;
+    c->H = full_h;
+    c->y0 = tile_y0;
+    c->rows = tile_rows;
+    c->npix = (size_t)full_w * tile_rows;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live.insert(c);
+    }
+    *out = c;
+    int rc = set_device(c);
+    if (rc)
+        return rc;
+    HIP_TRY(c, hipStreamCreate(&c->stream));
+    for (auto &ev : c->ev)
+        HIP_TRY(c, hipEventCreate(&ev));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rng, c->npix * 6 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_accum, c->npix * 3 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_normal, c->npix * 3 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_depth, c->npix * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_object_id, c->npix * sizeof(int)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rgb8, c->npix * 3));
+    HIP_TRY(c, hipMalloc((void **)&c->d_counters, 3 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_blue, PTRT_BLUE_NOISE_FLOATS * sizeof(float)));
+    HIP_TRY(c, hipMemsetAsync(c->d_rng, 0, c->npix * 6 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, c->npix * 3 * sizeof(float), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_rgb8, 0, c->npix * 3, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
+    // the blue-noise table is all zeros until the application installs one (bluenoise.cuh:46,189)
+    HIP_TRY(c, hipMemsetAsync(c->d_blue, 0, PTRT_BLUE_NOISE_FLOATS * sizeof(float), c->stream));
+    c->last_rgb8 = c->d_rgb8;
+    // default camera: Camera(aspect, 2, 1) of the Scene constructor (scene.cuh:748, camera.cuh:127-148)
+    const float aspect = (float)full_w / (float)full_h;
+    const float vw = 2.0f * aspect;
+    c->cam.origin = pt::f3{0, 0, 0};
+    c->cam.horizontal = pt::f3{vw, 0, 0};
+    c->cam.vertical = pt::f3{0, 2.0f, 0};
+    c->cam.llc = pt::f3{0.0f - vw * 0.5f, 0.0f - 2.0f * 0.5f, -1.0f};
+    c->cam.u = pt::f3{1, 0, 0};
+    c->cam.v = pt::f3{0, 1, 0};
+    c->cam.w = pt::f3{0, 0, 1};
+    c->cam.lens_radius = 0.0f;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTRT_OK;
+}
+
+void ptrt_destroy(ptrt_ctx *c) {
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        if (!c || !g_live.count(c))
+            return; // NULL or already destroyed: ignored, like a repeated cudaFree in the reference
+        g_live.erase(c);
+    }
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    dfree(c->d_materials);
+    dfree(c->d_lights);
+    dfree(c->d_rng);
+    dfree(c->d_accum);
+    dfree(c->d_normal);
+    dfree(c->d_depth);
+    dfree(c->d_object_id);
+    dfree(c->d_rgb8);
+    dfree(c->d_counters);
+    dfree(c->d_blue);
+    dfree(c->d_jump);
+    for (auto &ev : c->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ptrt_set_blue_noise(ptrt_ctx *c, const float *table) {
+    if (!ctx_live(c) || !table)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_blue_noise: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_blue, table, PTRT_BLUE_NOISE_FLOATS * sizeof(float), hipMemcpyHostToDevice,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTRT_OK;
+}
+
+int ptrt_reset_rng(ptrt_ctx *c, unsigned long long seed) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_reset_rng: bad context");
+    if (int rc = set_device(c))
+        return rc;
+    // bits needed for the largest global pixel index of this tile
+    const unsigned long long last = (unsigned long long)(c->y0 + c->rows) * (unsigned long long)c->W;
+    int bits = 1;
+    while ((last >> bits) != 0)
+        ++bits;
+    if (bits > c->n_jump) {
+        const std::vector<uint32_t> &J = jump_matrices(bits);
+        dfree(c->d_jump);
+        HIP_TRY(c, hipMalloc((void **)&c->d_jump, (size_t)bits * 800 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_jump, J.data(), (size_t)bits * 800 * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->n_jump = bits;
+    }
+    // curand_init's state scrambling (published cuRAND XORWOW; constants unverified)
+    const uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0;
+    const uint32_t t1 = 2591861531u * s1;
+    const uint32_t d0 = 6615241u + t1 + t0;
+    const uint32_t v0 = 123456789u + t0, v1 = 362436069u ^ t0, v2 = 521288629u + t1, v3 = 88675123u ^ t1,
+                   v4 = 5783321u + t0;
+    const int grid = (int)((c->npix + 255) / 256);
+    hipLaunchKernelGGL(pt::xorwow_init_kernel, dim3(grid), dim3(256), 0, c->stream, c->d_rng, c->W, c->rows, c->y0,
+                       d0, v0, v1, v2, v3, v4, c->d_jump, c->n_jump);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // the reference synchronises here too (scene.cuh:455)
+    c->rng_ready = true;
+    return PTRT_OK;
+}
+
+int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count, const ptrt_bvh_node *tlas_nodes,
+                         int tlas_node_count, const int32_t *tlas_mesh_indices, int tlas_index_count) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_upload_geometry: bad context");
+    if (!meshes || mesh_count <= 0 || !tlas_nodes || tlas_node_count <= 0 || !tlas_mesh_indices ||
+        tlas_index_count <= 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_upload_geometry: empty scene");
+    if (int rc = set_device(c))
+        return rc;
+
+    Relayout R;
+    std::vector<float4> recs((size_t)mesh_count * pt::MESH_REC_F4, f4(0, 0, 0, 0));
+    bool all_leaf = true;
+    std::string why;
+    for (int m = 0; m < mesh_count; ++m) {
+        const ptrt_mesh_desc &M = meshes[m];
+        if (!M.verts || !M.faces || !M.nodes || !M.prim_indices || M.node_count <= 0 || M.face_count <= 0 ||
+            M.vert_count <= 0 || M.prim_count <= 0)
+            return fail(c, PTRT_E_INVALID, "mesh %d: missing arrays (a mesh needs vertices, faces and a built BVH)", m);
+        for (int f = 0; f < M.face_count; ++f) {
+            const ptrt_tri &t = M.faces[f];
+            if (t.v0 < 0 || t.v1 < 0 || t.v2 < 0 || t.v0 >= M.vert_count || t.v1 >= M.vert_count ||
+                t.v2 >= M.vert_count)
+                return fail(c, PTRT_E_INVALID, "mesh %d: face %d references a vertex out of range", m, f);
+        }
+        bool bad = false;
+        auto emit_leaf = [&](int start, int count) -> int {
+            const int id = (int)R.leaves.size();
+            if (count > 0 && (start < 0 || start + count > M.prim_count)) {
+                bad = true;
+                count = 0;
+            }
+            R.leaves.push_back(make_int2((int)(R.tris.size() / 3), count));
+            for (int i = 0; i < count; ++i) {
+                const int fidx = M.prim_indices[start + i];
+                if (fidx < 0 || fidx >= M.face_count) {
+                    bad = true;
+                    R.tris.insert(R.tris.end(), 3, f4(0, 0, 0, 0));
+                    continue;
+                }
+                const ptrt_tri &t = M.faces[fidx];
+                const ptrt_vec3 &a = M.verts[t.v0], &b = M.verts[t.v1], &d = M.verts[t.v2];
+                // e1 = v1 - v0, e2 = v2 - v0: the same fp32 subtractions the reference performs per
+                // test (intersection.cuh:224-225), done once here
+                R.tris.push_back(f4(a.x, a.y, a.z, as_f(fidx)));
+                R.tris.push_back(f4(b.x - a.x, b.y - a.y, b.z - a.z, 0.0f));
+                R.tris.push_back(f4(d.x - a.x, d.y - a.y, d.z - a.z, 0.0f));
+            }
+            return id;
+        };
+        int depth = 0;
+        const int root = convert_tree(M.nodes, M.node_count, R.nodes, emit_leaf, depth, why);
+        if (root == INT32_MIN || bad)
+            return fail(c, PTRT_E_INVALID, "mesh %d: malformed BVH (%s)", m, bad ? "leaf range out of bounds" : why.c_str());
+        if (depth > 23)
+            return fail(c, PTRT_E_INVALID,
+                        "mesh %d: BVH is %d levels deep; the traversal stack (24 entries, as in the reference) needs <= 23",
+                        m, depth);
+        if (depth > R.max_depth)
+            R.max_depth = depth;
+        if (root >= 0)
+            all_leaf = false;
+        float4 *rec = &recs[(size_t)m * pt::MESH_REC_F4];
+        const ptrt_bvh_node &rn = M.nodes[0];
+        rec[0] = f4(rn.bmin.x, rn.bmin.y, rn.bmin.z, as_f(root));
+        rec[1] = f4(rn.bmax.x, rn.bmax.y, rn.bmax.z, as_f(M.has_transform ? 1 : 0));
+        for (int r = 0; r < 3; ++r) {
+            rec[2 + r] = f4(M.inverse[r * 4], M.inverse[r * 4 + 1], M.inverse[r * 4 + 2], M.inverse[r * 4 + 3]);
+            rec[5 + r] = f4(M.world[r * 4], M.world[r * 4 + 1], M.world[r * 4 + 2], M.world[r * 4 + 3]);
+            rec[8 + r] = f4(M.normal[r * 4], M.normal[r * 4 + 1], M.normal[r * 4 + 2], 0.0f);
+        }
+    }
+    // TLAS
+    std::vector<float4> tnodes;
+    std::vector<int2> tleaves;
+    bool bad = false;
+    auto emit_tleaf = [&](int start, int count) -> int {
+        if (count > 0 && (start < 0 || start + count > tlas_index_count)) {
+            bad = true;
+            count = 0;
+        }
+        tleaves.push_back(make_int2(start < 0 ? 0 : start, count));
+        return (int)tleaves.size() - 1;
+    };
+    int tdepth = 0;
+    const int troot = convert_tree(tlas_nodes, tlas_node_count, tnodes, emit_tleaf, tdepth, why);
+    if (troot == INT32_MIN || bad)
+        return fail(c, PTRT_E_INVALID, "malformed TLAS (%s)", bad ? "leaf range out of bounds" : why.c_str());
+    if (tdepth > 23)
+        return fail(c, PTRT_E_INVALID, "TLAS is %d levels deep; needs <= 23", tdepth);
+    std::vector<int> tids(tlas_mesh_indices, tlas_mesh_indices + tlas_index_count);
+    for (int id : tids)
+        if (id < 0 || id >= mesh_count)
+            return fail(c, PTRT_E_INVALID, "TLAS references mesh %d of %d", id, mesh_count);
+
+    free_scene(c);
+    c->n_meshes = mesh_count;
+    c->h_mesh_recs = recs;
+    if (int rc = push_mesh_recs(c))
+        return rc;
+    if (int rc = upload(c, c->d_nodes, R.nodes))
+        return rc;
+    if (int rc = upload(c, c->d_leaves, R.leaves))
+        return rc;
+    if (int rc = upload(c, c->d_tris, R.tris))
+        return rc;
+    if (int rc = upload(c, c->d_tlas_nodes, tnodes))
+        return rc;
+    if (int rc = upload(c, c->d_tlas_leaves, tleaves))
+        return rc;
+    if (int rc = upload(c, c->d_tlas_mesh_ids, tids))
+        return rc;
+    c->tlas_root_min[0] = tlas_nodes[0].bmin.x;
+    c->tlas_root_min[1] = tlas_nodes[0].bmin.y;
+    c->tlas_root_min[2] = tlas_nodes[0].bmin.z;
+    c->tlas_root_max[0] = tlas_nodes[0].bmax.x;
+    c->tlas_root_max[1] = tlas_nodes[0].bmax.y;
+    c->tlas_root_max[2] = tlas_nodes[0].bmax.z;
+    c->tlas_root_ref = troot;
+    c->tlas_single_leaf = troot < 0;
+    c->all_single_leaf = all_leaf;
+    c->stack_entries = R.max_depth < 1 ? 1 : R.max_depth;
+    c->have_geometry = true;
+    return PTRT_OK;
+}
+
+int ptrt_upload_materials(ptrt_ctx *c, const ptrt_materials *m) {
+    if (!ctx_live(c) || !m || m->count <= 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_upload_materials: bad argument");
+    if (!m->albedo || !m->specular || !m->metallic || !m->roughness || !m->emission || !m->ior || !m->transmission ||
+        !m->transmission_roughness || !m->clearcoat || !m->clearcoat_roughness || !m->sheen || !m->sheen_tint ||
+        !m->iridescence || !m->iridescence_thickness)
+        return fail(c, PTRT_E_INVALID, "ptrt_upload_materials: a required array is NULL");
+    if (int rc = set_device(c))
+        return rc;
+    std::vector<float4> recs((size_t)m->count * 6);
+    c->h_shadow_skip.assign(m->count, 0);
+    bool full = false;
+    for (int i = 0; i < m->count; ++i) {
+        float4 *r = &recs[(size_t)i * 6];
+        r[0] = f4(m->albedo[i].x, m->albedo[i].y, m->albedo[i].z, m->metallic[i]);
+        r[1] = f4(m->specular[i].x, m->specular[i].y, m->specular[i].z, m->roughness[i]);
+        r[2] = f4(m->emission[i].x, m->emission[i].y, m->emission[i].z, m->transmission[i]);
+        r[3] = f4(m->sheen_tint[i].x, m->sheen_tint[i].y, m->sheen_tint[i].z, m->ior[i]);
+        r[4] = f4(m->transmission_roughness[i], m->clearcoat[i], m->clearcoat_roughness[i], m->iridescence[i]);
+        r[5] = f4(m->iridescence_thickness[i], m->sheen[i], 0.0f, 0.0f);
+        c->h_shadow_skip[i] = (m->transmission[i] > 0.5f) ? 1 : 0;
+        // the lean shading variant drops branches that are provably dead when all of these are <= 0
+        if (!(m->transmission[i] <= 0.0f) || !(m->clearcoat[i] <= 0.0f) || !(m->iridescence[i] <= 0.0f) ||
+            !(m->sheen[i] <= 0.0f))
+            full = true;
+    }
+    if (int rc = upload(c, c->d_materials, recs))
+        return rc;
+    c->n_materials = m->count;
+    c->mats_full = full;
+    c->have_materials = true;
+    if (c->have_geometry)
+        return push_mesh_recs(c);
+    return PTRT_OK;
+}
+
+int ptrt_upload_lights(ptrt_ctx *c, const ptrt_light *lights, int n) {
+    if (!ctx_live(c) || n < 0 || (n > 0 && !lights))
+        return fail(c, PTRT_E_INVALID, "ptrt_upload_lights: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    std::vector<float4> recs((size_t)n * 4);
+    for (int i = 0; i < n; ++i) {
+        const ptrt_light &l = lights[i];
+        if (l.type < 0 || l.type > 2)
+            return fail(c, PTRT_E_INVALID, "light %d: unknown type %d", i, l.type);
+        recs[(size_t)i * 4 + 0] = f4(l.position.x, l.position.y, l.position.z, as_f(l.type));
+        recs[(size_t)i * 4 + 1] = f4(l.direction.x, l.direction.y, l.direction.z, l.intensity);
+        recs[(size_t)i * 4 + 2] = f4(l.color.x, l.color.y, l.color.z, l.range);
+        recs[(size_t)i * 4 + 3] = f4(l.inner_cone, l.outer_cone, l.radius, 0.0f);
+    }
+    if (int rc = upload(c, c->d_lights, recs))
+        return rc;
+    c->n_lights = n;
+    return PTRT_OK;
+}
+
+int ptrt_set_camera(ptrt_ctx *c, const ptrt_camera *cam) {
+    if (!ctx_live(c) || !cam)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_camera: bad argument");
+    auto v = [](const ptrt_vec3 &a) { return pt::f3{a.x, a.y, a.z}; };
+    c->cam.origin = v(cam->origin);
+    c->cam.llc = v(cam->lower_left_corner);
+    c->cam.horizontal = v(cam->horizontal);
+    c->cam.vertical = v(cam->vertical);
+    c->cam.u = v(cam->u);
+    c->cam.v = v(cam->v);
+    c->cam.w = v(cam->w);
+    c->cam.lens_radius = cam->lens_radius;
+    return PTRT_OK;
+}
+
+int ptrt_set_sky(ptrt_ctx *c, const ptrt_vec3 *top, const ptrt_vec3 *bottom, int use_sky) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_set_sky: bad context");
+    if (top)
+        c->sky_top = pt::f3{top->x, top->y, top->z};
+    if (bottom)
+        c->sky_bottom = pt::f3{bottom->x, bottom->y, bottom->z};
+    c->use_sky = use_sky ? 1 : 0;
+    return PTRT_OK;
+}
+
+int ptrt_upload_scene(ptrt_ctx *c, const ptrt_scene_desc *s) {
+    if (!ctx_live(c) || !s)
+        return fail(c, PTRT_E_INVALID, "ptrt_upload_scene: bad argument");
+    if (int rc = ptrt_upload_geometry(c, s->meshes, s->mesh_count, s->tlas_nodes, s->tlas_node_count,
+                                      s->tlas_mesh_indices, s->tlas_index_count))
+        return rc;
+    if (int rc = ptrt_upload_materials(c, &s->materials))
+        return rc;
+    if (int rc = ptrt_upload_lights(c, s->lights, s->light_count))
+        return rc;
+    if (int rc = ptrt_set_camera(c, &s->camera))
+        return rc;
+    return ptrt_set_sky(c, &s->sky_top, &s->sky_bottom, s->use_sky);
+}
+
+int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_render: bad context");
+    if (!c->have_geometry || !c->have_materials)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_render: %s not uploaded", c->have_geometry ? "materials" : "geometry");
+    if (c->n_materials < c->n_meshes)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_render: %d materials for %d meshes", c->n_materials, c->n_meshes);
+    if (!c->rng_ready)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_render: generator states not initialised (ptrt_reset_rng)");
+    if (spp < 1 || max_depth < 1)
+        return fail(c, PTRT_E_INVALID, "ptrt_render: spp=%d max_depth=%d", spp, max_depth);
+    if (int rc = set_device(c))
+        return rc;
+    pt::KParams K = make_params(c);
+    K.spp = spp;
+    K.max_depth = max_depth;
+    K.frame_count = frame_index;
+    K.rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
+    c->last_rgb8 = K.rgb8;
+    if (c->count_rays)
+        K.counters = c->d_counters;
+    const int tiles_y = (c->rows + 7) / 8;
+    const int grid = K.tiles_x * tiles_y;
+    const int geom = pick_geom(c);
+    const bool full = c->mats_full || c->force_full;
+    const size_t lds = (geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2);
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (geom == 0)
+        launch_trace<0>(c, K, full, grid, lds);
+    else if (geom == 1)
+        launch_trace<1>(c, K, full, grid, lds);
+    else
+        launch_trace<2>(c, K, full, grid, lds);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    c->timed = true;
+    if (out_rgb8 && !out_is_device) {
+        HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PTRT_OK;
+}
+
+int ptrt_sync(ptrt_ctx *c) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_sync: bad context");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTRT_OK;
+}
+
+int ptrt_last_kernel_ms(ptrt_ctx *c, float *trace_ms, float *tonemap_ms) {
+    if (!ctx_live(c) || !c->timed)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_last_kernel_ms: nothing rendered yet");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipEventSynchronize(c->ev[1]));
+    float ms = 0.0f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    if (trace_ms)
+        *trace_ms = ms;
+    if (tonemap_ms)
+        *tonemap_ms = 0.0f; // the tonemap is fused into the path-trace kernel
+    return PTRT_OK;
+}
+
+void *ptrt_device_buffer(ptrt_ctx *c, int kind) {
+    if (!ctx_live(c))
+        return nullptr;
+    switch (kind) {
+    case PTRT_BUF_ACCUM: return c->d_accum;
+    case PTRT_BUF_NORMAL: return c->d_normal;
+    case PTRT_BUF_DEPTH: return c->d_depth;
+    case PTRT_BUF_OBJECT_ID: return c->d_object_id;
+    case PTRT_BUF_RGB8: return c->last_rgb8;
+    default: return nullptr;
+    }
+}
+
+int ptrt_read_buffer(ptrt_ctx *c, int kind, void *dst, size_t bytes) {
+    if (!ctx_live(c) || !dst)
+        return fail(c, PTRT_E_INVALID, "ptrt_read_buffer: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    size_t need = 0;
+    const void *src = nullptr;
+    switch (kind) {
+    case PTRT_BUF_ACCUM: need = c->npix * 12; src = c->d_accum; break;
+    case PTRT_BUF_NORMAL: need = c->npix * 12; src = c->d_normal; break;
+    case PTRT_BUF_DEPTH: need = c->npix * 4; src = c->d_depth; break;
+    case PTRT_BUF_OBJECT_ID: need = c->npix * 4; src = c->d_object_id; break;
+    case PTRT_BUF_RGB8: need = c->npix * 3; src = c->last_rgb8; break;
+    case PTRT_BUF_RNG: need = c->npix * 24; break;
+    default: return fail(c, PTRT_E_INVALID, "ptrt_read_buffer: unknown kind %d", kind);
+    }
+    if (bytes < need)
+        return fail(c, PTRT_E_INVALID, "ptrt_read_buffer: destination holds %zu bytes, need %zu", bytes, need);
+    if (kind == PTRT_BUF_RNG) {
+        uint32_t *tmp = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&tmp, need));
+        hipLaunchKernelGGL(pt::rng_planar_to_aos, dim3((unsigned)((c->npix + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_rng, tmp, c->npix);
+        hipError_t e = hipMemcpyAsync(dst, tmp, need, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        (void)hipFree(tmp);
+        if (e != hipSuccess)
+            return fail(c, PTRT_E_HIP, "RNG read-back failed: %s", hipGetErrorString(e));
+        return PTRT_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTRT_OK;
+}
+
+int ptrt_write_rng(ptrt_ctx *c, const uint32_t *states, size_t bytes) {
+    if (!ctx_live(c) || !states || bytes < c->npix * 24)
+        return fail(c, PTRT_E_INVALID, "ptrt_write_rng: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    uint32_t *tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&tmp, c->npix * 24));
+    hipError_t e = hipMemcpyAsync(tmp, states, c->npix * 24, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pt::rng_aos_to_planar, dim3((unsigned)((c->npix + 255) / 256)), dim3(256), 0, c->stream, tmp,
+                           c->d_rng, c->npix);
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess)
+        return fail(c, PTRT_E_HIP, "RNG upload failed: %s", hipGetErrorString(e));
+    c->rng_ready = true;
+    return PTRT_OK;
+}
+
+int ptrt_trace_rays(ptrt_ctx *c, const float *origins, const float *directions, int n, ptrt_hit *out) {
+    static_assert(sizeof(pt::HitOut) == sizeof(ptrt_hit), "HitOut must mirror ptrt_hit");
+    if (!ctx_live(c) || !origins || !directions || !out || n < 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_trace_rays: bad argument");
+    if (!c->have_geometry)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_trace_rays: geometry not uploaded");
+    if (n == 0)
+        return PTRT_OK;
+    if (int rc = set_device(c))
+        return rc;
+    float *d_o = nullptr, *d_d = nullptr;
+    pt::HitOut *d_h = nullptr;
+    int rc = PTRT_OK;
+    hipError_t e = hipMalloc((void **)&d_o, (size_t)n * 12);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_d, (size_t)n * 12);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_h, (size_t)n * sizeof(pt::HitOut));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_d, directions, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        pt::KParams K = make_params(c);
+        const int geom = pick_geom(c);
+        const size_t lds = (geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2);
+        const int grid = (n + 63) / 64;
+        if (geom == 0)
+            hipLaunchKernelGGL(pt::trace_rays_kernel<0>, dim3(grid), dim3(64), lds, c->stream, K, d_o, d_d, n, d_h);
+        else if (geom == 1)
+            hipLaunchKernelGGL(pt::trace_rays_kernel<1>, dim3(grid), dim3(64), lds, c->stream, K, d_o, d_d, n, d_h);
+        else
+            hipLaunchKernelGGL(pt::trace_rays_kernel<2>, dim3(grid), dim3(64), lds, c->stream, K, d_o, d_d, n, d_h);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, d_h, (size_t)n * sizeof(pt::HitOut), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+        rc = fail(c, PTRT_E_HIP, "ptrt_trace_rays: %s", hipGetErrorString(e));
+    (void)hipFree(d_o);
+    (void)hipFree(d_d);
+    (void)hipFree(d_h);
+    return rc;
+}
+
+int ptrt_get_stats(ptrt_ctx *c, ptrt_stats *out) {
+    if (!ctx_live(c) || !out)
+        return fail(c, PTRT_E_INVALID, "ptrt_get_stats: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof h, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->extension_rays = h[0];
+    out->shadow_rays = h[1];
+    out->paths = h[2];
+    return PTRT_OK;
+}
+
+int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
+    if (!ctx_live(c) || !name)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_option: bad argument");
+    const std::string n(name);
+    if (n == "count_rays")
+        c->count_rays = value ? 1 : 0;
+    else if (n == "force_geom") { // -1 auto; 1 / 2 force a more general traversal variant (tests)
+        if (value < -1 || value > 2)
+            return fail(c, PTRT_E_INVALID, "force_geom must be -1..2");
+        c->force_geom = (int)value;
+    } else if (n == "force_full")
+        c->force_full = value ? 1 : 0;
+    else
+        return fail(c, PTRT_E_INVALID, "unknown option '%s'", name);
+    return PTRT_OK;
+}
+
+// test hook (not part of the drop-in surface): the kernels' deterministic math on the GPU
+int ptrt_debug_detmath(ptrt_ctx *c, int op, const float *x, const float *y, int n, float *out) {
+    if (!ctx_live(c) || !x || !out || n <= 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_debug_detmath: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&dx, (size_t)n * 4));
+    HIP_TRY(c, hipMalloc((void **)&dy, (size_t)n * 4));
+    HIP_TRY(c, hipMalloc((void **)&dout, (size_t)n * 4));
+    HIP_TRY(c, hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(dy, y ? y : x, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pt::detmath_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, dx, dy, n, dout);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    (void)hipFree(dout);
+    return PTRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,262 @@
+// ptrt_host_capi.cpp -- flat C entry points over the C++ `Scene` mirror
+// (host/ptrt/scene.hpp) so that Python (ctypes) tests, bench.py and other FFI
+// callers can drive the same host API a C++ application uses.  One function per
+// Scene method; C++ exceptions become negative return codes + hs_last_error().
+#include "../host/ptrt/scene.hpp"
+
+#include <string>
+
+namespace {
+thread_local std::string g_err;
+
+Material from_floats(const float *m) { // 27 floats, field order of hs_material_default
+    Material r;
+    r.albedo = vec3(m[0], m[1], m[2]);
+    r.specular = vec3(m[3], m[4], m[5]);
+    r.metallic = m[6];
+    r.roughness = m[7];
+    r.emission = vec3(m[8], m[9], m[10]);
+    r.ior = m[11];
+    r.transmission = m[12];
+    r.transmissionRoughness = m[13];
+    r.clearcoat = m[14];
+    r.clearcoatRoughness = m[15];
+    r.subsurfaceColor = vec3(m[16], m[17], m[18]);
+    r.subsurfaceRadius = m[19];
+    r.anisotropy = m[20];
+    r.sheen = m[21];
+    r.sheenTint = vec3(m[22], m[23], m[24]);
+    r.iridescence = m[25];
+    r.iridescenceThickness = m[26];
+    return r;
+}
+void to_floats(const Material &r, float *m) {
+    m[0] = r.albedo.x; m[1] = r.albedo.y; m[2] = r.albedo.z;
+    m[3] = r.specular.x; m[4] = r.specular.y; m[5] = r.specular.z;
+    m[6] = r.metallic; m[7] = r.roughness;
+    m[8] = r.emission.x; m[9] = r.emission.y; m[10] = r.emission.z;
+    m[11] = r.ior; m[12] = r.transmission; m[13] = r.transmissionRoughness;
+    m[14] = r.clearcoat; m[15] = r.clearcoatRoughness;
+    m[16] = r.subsurfaceColor.x; m[17] = r.subsurfaceColor.y; m[18] = r.subsurfaceColor.z;
+    m[19] = r.subsurfaceRadius; m[20] = r.anisotropy; m[21] = r.sheen;
+    m[22] = r.sheenTint.x; m[23] = r.sheenTint.y; m[24] = r.sheenTint.z;
+    m[25] = r.iridescence; m[26] = r.iridescenceThickness;
+}
+int mesh_index(Scene *s, Mesh *m) {
+    for (size_t i = 0; i < s->getMeshCount(); ++i)
+        if (s->getMesh(i) == m)
+            return (int)i;
+    return -1;
+}
+} // namespace
+
+#define HS_TRY(body)                                                                                            \
+    try {                                                                                                       \
+        body;                                                                                                   \
+    } catch (const std::exception &e) {                                                                         \
+        g_err = e.what();                                                                                       \
+        return -1;                                                                                              \
+    }
+
+extern "C" {
+
+const char *hs_last_error(void) { return g_err.c_str(); }
+
+void hs_material_default(float *out27) { to_floats(Material(), out27); }
+// Material(albedo, roughness, metallic) constructor (material_lib.cuh:91-104)
+void hs_material_make(const float *albedo3, float roughness, float metallic, float *out27) {
+    to_floats(Material(vec3(albedo3[0], albedo3[1], albedo3[2]), roughness, metallic), out27);
+}
+
+void *hs_scene_create(int w, int h, int tile_y0, int tile_rows, int device) {
+    try {
+        return new Scene(w, h, tile_y0, tile_rows, device);
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void hs_scene_destroy(void *s) { delete static_cast<Scene *>(s); }
+void *hs_backend(void *s) { return static_cast<Scene *>(s)->backend(); }
+
+int hs_init_blue_noise(void *s) { HS_TRY(static_cast<Scene *>(s)->initBlueNoise()); return 0; }
+void hs_blue_noise_table(float *out8192) {
+    const std::vector<float> &t = ptrtBlueNoiseTable();
+    std::memcpy(out8192, t.data(), t.size() * sizeof(float));
+}
+// raw generator, for tests of the relaxation itself at small sizes
+void hs_blue_noise_generate(int size, int iterations, float *out) {
+    std::vector<float> t = BlueNoiseGenerator::generateBlueNoise2D(size, iterations);
+    std::memcpy(out, t.data(), t.size() * sizeof(float));
+}
+
+int hs_add_cube(void *s, const float *mat27) {
+    Scene *sc = static_cast<Scene *>(s);
+    HS_TRY(return mesh_index(sc, sc->addCube(from_floats(mat27))));
+}
+int hs_add_sphere(void *s, int segments, const float *mat27) {
+    Scene *sc = static_cast<Scene *>(s);
+    HS_TRY(return mesh_index(sc, sc->addSphere(segments, from_floats(mat27))));
+}
+int hs_add_plane_xz(void *s, float y, float half, const float *mat27) {
+    Scene *sc = static_cast<Scene *>(s);
+    HS_TRY(return mesh_index(sc, sc->addPlaneXZ(y, half, from_floats(mat27))));
+}
+int hs_add_triangles(void *s, const float *verts9, int n_tris, const float *mat27) {
+    Scene *sc = static_cast<Scene *>(s);
+    std::vector<Triangle> tris;
+    tris.reserve(n_tris);
+    for (int i = 0; i < n_tris; ++i) {
+        const float *v = verts9 + (size_t)i * 9;
+        tris.emplace_back(vec3(v[0], v[1], v[2]), vec3(v[3], v[4], v[5]), vec3(v[6], v[7], v[8]));
+    }
+    HS_TRY(return mesh_index(sc, sc->addTriangles(tris, from_floats(mat27))));
+}
+int hs_add_mesh_obj(void *s, const char *path, const float *mat27) {
+    Scene *sc = static_cast<Scene *>(s);
+    HS_TRY(return mesh_index(sc, sc->addMesh(path, from_floats(mat27))));
+}
+int hs_add_checkerboard(void *s, float y, int tiles, float tile_size, const float *white27, const float *black27) {
+    HS_TRY(static_cast<Scene *>(s)->addCheckerboardPlaneXZ(y, tiles, tile_size, from_floats(white27),
+                                                            from_floats(black27)));
+    return 0;
+}
+
+// op: 0 scale(vec3) 1 translate 2 moveTo 3 rotateSelfEulerXYZ 4 setPosition 5 setRotation 6 transform.setScale
+int hs_mesh_op(void *s, int mesh, int op, float x, float y, float z) {
+    Mesh *m = static_cast<Scene *>(s)->getMesh((size_t)mesh);
+    if (!m) {
+        g_err = "no such mesh";
+        return -1;
+    }
+    const vec3 v(x, y, z);
+    switch (op) {
+    case 0: m->scale(v); break;
+    case 1: m->translate(v); break;
+    case 2: m->moveTo(v); break;
+    case 3: m->rotateSelfEulerXYZ(v); break;
+    case 4: m->setPosition(v); break;
+    case 5: m->setRotation(v); break;
+    case 6: m->transform.setScale(v); m->transform.updateMatrices(); break;
+    default: g_err = "unknown mesh op"; return -1;
+    }
+    return 0;
+}
+// replaces the vertex array of a mesh in place (the dynamic-geometry caller,
+// PTRTtransfer.cuh:2249-2270: new positions, same topology)
+int hs_mesh_set_vertices(void *s, int mesh, const float *xyz, int n_verts) {
+    Mesh *m = static_cast<Scene *>(s)->getMesh((size_t)mesh);
+    if (!m || (size_t)n_verts != m->vertices.size()) {
+        g_err = "vertex count mismatch";
+        return -1;
+    }
+    for (int i = 0; i < n_verts; ++i)
+        m->vertices[i] = vec3(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]);
+    m->bvhDirty = true;
+    m->vertsDirty = true;
+    return 0;
+}
+int hs_mesh_counts(void *s, int mesh, int *n_verts, int *n_faces, int *n_nodes) {
+    Mesh *m = static_cast<Scene *>(s)->getMesh((size_t)mesh);
+    if (!m)
+        return -1;
+    *n_verts = (int)m->vertices.size();
+    *n_faces = (int)m->faces.size();
+    *n_nodes = (int)m->bvhNodes.size();
+    return 0;
+}
+
+void hs_add_point_light(void *s, const float *pos3, const float *col3, float intensity, float range, float radius) {
+    static_cast<Scene *>(s)->addPointLight(vec3(pos3[0], pos3[1], pos3[2]), vec3(col3[0], col3[1], col3[2]), intensity,
+                                           range, radius);
+}
+void hs_add_directional_light(void *s, const float *dir3, const float *col3, float intensity) {
+    static_cast<Scene *>(s)->addDirectionalLight(vec3(dir3[0], dir3[1], dir3[2]), vec3(col3[0], col3[1], col3[2]),
+                                                 intensity);
+}
+void hs_add_spot_light(void *s, const float *pos3, const float *dir3, const float *col3, float intensity, float inner,
+                       float outer, float range, float radius) {
+    static_cast<Scene *>(s)->addSpotLight(vec3(pos3[0], pos3[1], pos3[2]), vec3(dir3[0], dir3[1], dir3[2]),
+                                          vec3(col3[0], col3[1], col3[2]), intensity, inner, outer, range, radius);
+}
+void hs_move_light_to(void *s, int i, const float *pos3) {
+    static_cast<Scene *>(s)->moveLightTo((size_t)i, vec3(pos3[0], pos3[1], pos3[2]));
+}
+
+void hs_set_camera(void *s, const float *from3, const float *at3, const float *up3, float vfov, float aperture,
+                   float focus_dist) {
+    static_cast<Scene *>(s)->setCamera(vec3(from3[0], from3[1], from3[2]), vec3(at3[0], at3[1], at3[2]),
+                                       vec3(up3[0], up3[1], up3[2]), vfov, aperture, focus_dist);
+}
+void hs_move_camera(void *s, const float *pos3) { static_cast<Scene *>(s)->moveCamera(vec3(pos3[0], pos3[1], pos3[2])); }
+void hs_look_camera_at(void *s, const float *at3) {
+    static_cast<Scene *>(s)->lookCameraAt(vec3(at3[0], at3[1], at3[2]));
+}
+void hs_set_sky_gradient(void *s, const float *top3, const float *bottom3) {
+    static_cast<Scene *>(s)->setSkyGradient(vec3(top3[0], top3[1], top3[2]), vec3(bottom3[0], bottom3[1], bottom3[2]));
+}
+void hs_disable_sky(void *s) { static_cast<Scene *>(s)->disableSky(); }
+
+void hs_set_bvh_leaf_target(void *s, int target, int tol) { static_cast<Scene *>(s)->setBVHLeafTarget(target, tol); }
+void hs_set_max_bounce_depth(void *s, int d) { static_cast<Scene *>(s)->setMaxBounceDepth(d); }
+void hs_set_samples_per_pixel(void *s, int spp) { static_cast<Scene *>(s)->setSamplesPerPixel(spp); }
+void hs_set_denoiser_enabled(void *s, int e) { static_cast<Scene *>(s)->setDenoiserEnabled(e != 0); }
+void hs_set_bloom_enabled(void *s, int e) { static_cast<Scene *>(s)->setBloomEnabled(e != 0); }
+void hs_set_performance_preset(void *s, const char *name) { static_cast<Scene *>(s)->setPerformancePreset(name); }
+void hs_get_settings(void *s, int *spp, int *depth, int *denoiser, int *bloom, float *scale) {
+    const Scene::PerformanceSettings &p = static_cast<Scene *>(s)->getPerformanceSettings();
+    *spp = p.samplesPerPixel;
+    *depth = p.maxBounceDepth;
+    *denoiser = p.enableDenoiser;
+    *bloom = p.enableBloom;
+    *scale = p.resolutionScale;
+}
+int hs_set_mesh_material(void *s, int mesh, const float *mat27) {
+    Scene *sc = static_cast<Scene *>(s);
+    sc->setMeshMaterial((size_t)mesh, from_floats(mat27));
+    sc->commitMaterialChanges();
+    return 0;
+}
+
+int hs_upload(void *s) { HS_TRY(static_cast<Scene *>(s)->uploadToGPU()); return 0; }
+int hs_commit_object_changes(void *s) { HS_TRY(static_cast<Scene *>(s)->commitObjectChanges()); return 0; }
+int hs_render_to_device(void *s, void *device_pixels) {
+    HS_TRY(static_cast<Scene *>(s)->render_to_device(static_cast<unsigned char *>(device_pixels)));
+    return 0;
+}
+int hs_render_to_host(void *s, void *host_pixels) {
+    HS_TRY(static_cast<Scene *>(s)->render_to_host(static_cast<unsigned char *>(host_pixels)));
+    return 0;
+}
+int hs_get_frame_count(void *s) { return static_cast<Scene *>(s)->getFrameCount(); }
+void hs_set_frame_count(void *s, int f) { static_cast<Scene *>(s)->setFrameCount(f); }
+int hs_trace_single_ray(void *s, const float *o3, const float *d3, ptrt_hit *out) {
+    HitInfo h = static_cast<Scene *>(s)->traceSingleRay(vec3(o3[0], o3[1], o3[2]), vec3(d3[0], d3[1], d3[2]));
+    out->hit = h.hit;
+    out->t = h.t;
+    out->point = {h.point.x, h.point.y, h.point.z};
+    out->normal = {h.normal.x, h.normal.y, h.normal.z};
+    out->mesh_index = h.mesh_index;
+    out->front_face = h.front_face;
+    out->u = h.u;
+    out->v = h.v;
+    out->face_index = h.face_index;
+    out->local_point = {h.localPoint.x, h.localPoint.y, h.localPoint.z};
+    return 0;
+}
+int hs_save_ppm(void *s, const char *path, unsigned char *pixels) {
+    HS_TRY(static_cast<Scene *>(s)->saveAsPPM(path, pixels));
+    return 0;
+}
+
+// flattened scene (host pointers owned by the Scene, valid until it is mutated)
+const ptrt_scene_desc *hs_flatten(void *s) {
+    try {
+        return &static_cast<Scene *>(s)->flatten();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,240 @@
+// ptrt/mesh.hpp -- host-side triangle mesh + BLAS builder of the Scene API.
+//
+// Mirrors `class Mesh` (reference: src/pathtracer/scene/mesh.cuh:49-232) minus the
+// device pointers: all device memory belongs to the back-end context
+// (include/ptrt.h), the mesh only keeps host arrays and dirty flags.
+#pragma once
+#include "../../../include/ptrt.h"
+#include "math.hpp"
+
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct Triangle { // src/common/triangle.cuh:15-28 (the fields addTriangles reads)
+    vec3 v0, v1, v2;
+    Triangle() = default;
+    Triangle(const vec3 &a, const vec3 &b, const vec3 &c) : v0(a), v1(b), v2(c) {}
+};
+
+using Tri = ptrt_tri;                // mesh.cuh:45-47
+using DeviceBVHNode = ptrt_bvh_node; // mesh.cuh:37-43 (same 40-byte layout)
+
+namespace ptrt_detail {
+struct BuildRef {
+    int id;
+    vec3 c;
+    AABB b;
+};
+// Median split on the longest CENTROID axis, leaf when n <= leafMax, nodes in
+// pre-order, leaf primitives appended in range order (mesh.cuh:403-492 for
+// triangles, scene.cuh:458-594 for the TLAS).  std::nth_element makes the
+// topology libstdc++-specific; it is an input of the path, not part of it.
+inline int build_bvh_range(std::vector<BuildRef> &R, int begin, int end, int leafMax,
+                           std::vector<DeviceBVHNode> &nodes, std::vector<int> &prims) {
+    AABB bb = AABB::make_invalid(), cb = AABB::make_invalid();
+    for (int i = begin; i < end; ++i) {
+        bb.expand(R[i].b);
+        cb.expand(R[i].c);
+    }
+    const int n = end - begin;
+    const int me = (int)nodes.size();
+    nodes.emplace_back();
+    nodes[me].bmin = {bb.bmin.x, bb.bmin.y, bb.bmin.z};
+    nodes[me].bmax = {bb.bmax.x, bb.bmax.y, bb.bmax.z};
+    nodes[me].left = nodes[me].right = nodes[me].start = -1;
+    nodes[me].count = 0;
+    if (n <= leafMax) {
+        nodes[me].start = (int)prims.size();
+        nodes[me].count = n;
+        for (int i = begin; i < end; ++i)
+            prims.push_back(R[i].id);
+        return me;
+    }
+    vec3 e = cb.extent();
+    const int axis = (e.x > e.y && e.x > e.z) ? 0 : ((e.y > e.z) ? 1 : 2);
+    const int mid = (begin + end) / 2;
+    std::nth_element(R.begin() + begin, R.begin() + mid, R.begin() + end,
+                     [axis](const BuildRef &A, const BuildRef &B) { return A.c[axis] < B.c[axis]; });
+    const int L = build_bvh_range(R, begin, mid, leafMax, nodes, prims);
+    const int Rn = build_bvh_range(R, mid, end, leafMax, nodes, prims);
+    nodes[me].left = L;
+    nodes[me].right = Rn;
+    return me;
+}
+} // namespace ptrt_detail
+
+class Mesh {
+  public:
+    std::vector<vec3> vertices;
+    std::vector<Tri> faces;
+    std::vector<DeviceBVHNode> bvhNodes;
+    std::vector<int> bvhPrimIndices;
+    bool bvhDirty = true;
+    bool vertsDirty = true;
+    int bvhLeafTarget = 12; // mesh.cuh:65-66
+    int bvhLeafTol = 5;
+    Transform3D transform;
+    AABB localAABB = AABB::make_invalid();
+
+    // unit cube centred at the origin, 8 vertices / 12 faces (mesh.cuh:221-229)
+    Mesh() {
+        for (int i = 0; i < 8; ++i) {
+            const bool xh = ((i & 3) == 1) || ((i & 3) == 2);
+            vertices.emplace_back(xh ? 0.5f : -0.5f, (i & 2) ? 0.5f : -0.5f, (i & 4) ? 0.5f : -0.5f);
+        }
+        static const int F[12][3] = {{0, 2, 1}, {0, 3, 2}, {4, 5, 6}, {4, 6, 7}, {0, 1, 5}, {0, 5, 4},
+                                     {3, 7, 6}, {3, 6, 2}, {0, 4, 7}, {0, 7, 3}, {1, 2, 6}, {1, 6, 5}};
+        for (auto &f : F)
+            faces.push_back({f[0], f[1], f[2]});
+    }
+
+    // Wavefront OBJ: `v` and `f` records only, polygons fanned, negative indices
+    // relative, a/b/c index forms accepted, vertices re-centred on their mean
+    // (mesh.cuh:238-323).
+    explicit Mesh(const std::string &path) {
+        std::ifstream in(path);
+        if (!in)
+            throw std::runtime_error("Mesh: cannot open " + path);
+        double sx = 0, sy = 0, sz = 0;
+        size_t nv = 0;
+        std::string line, key;
+        std::vector<int> idx;
+        while (std::getline(in, line)) {
+            if (line.empty() || line[0] == '#')
+                continue;
+            std::istringstream ss(line);
+            ss >> key;
+            if (key == "v") {
+                float x, y, z;
+                ss >> x >> y >> z;
+                if (!ss.fail()) {
+                    vertices.emplace_back(x, y, z);
+                    sx += x; sy += y; sz += z;
+                    ++nv;
+                }
+            } else if (key == "f") {
+                idx.clear();
+                int id;
+                while (ss >> id) {
+                    idx.push_back(id < 0 ? (int)nv + id : id - 1);
+                    while (ss.peek() == '/') {
+                        ss.get();
+                        if (ss.peek() == '/')
+                            ss.get();
+                        int skipped;
+                        ss >> skipped;
+                    }
+                }
+                for (size_t i = 1; i + 1 < idx.size(); ++i)
+                    faces.push_back({idx[0], idx[i], idx[i + 1]});
+            }
+        }
+        if (in.bad())
+            throw std::runtime_error("Mesh: hardware error reading " + path);
+        if (vertices.empty() || faces.empty())
+            throw std::runtime_error("Mesh: no valid geometry in " + path);
+        const float cx = (float)(sx / nv), cy = (float)(sy / nv), cz = (float)(sz / nv);
+        for (auto &v : vertices) {
+            v.x -= cx; v.y -= cy; v.z -= cz;
+        }
+    }
+
+    Mesh(const Mesh &) = delete;
+    Mesh &operator=(const Mesh &) = delete;
+
+    size_t faceCount() const { return faces.size(); }
+    size_t vertexCount() const { return vertices.size(); }
+
+    void setBVHLeafParams(int target, int tol = 5) {
+        bvhLeafTarget = target < 1 ? 1 : target;
+        bvhLeafTol = tol < 0 ? 0 : tol;
+        bvhDirty = true;
+    }
+
+    // mesh.cuh:403-492
+    void buildBVH() {
+        bvhNodes.clear();
+        bvhPrimIndices.clear();
+        if (faces.empty()) {
+            bvhDirty = false;
+            return;
+        }
+        std::vector<ptrt_detail::BuildRef> refs;
+        refs.reserve(faces.size());
+        for (int i = 0; i < (int)faces.size(); ++i) {
+            const vec3 &a = vertices[faces[i].v0], &b = vertices[faces[i].v1], &c = vertices[faces[i].v2];
+            ptrt_detail::BuildRef r;
+            r.id = i;
+            r.b = {a, a};
+            r.b.expand(b);
+            r.b.expand(c);
+            r.c = (a + b + c) * (1.0f / 3.0f);
+            refs.push_back(r);
+        }
+        ptrt_detail::build_bvh_range(refs, 0, (int)refs.size(), bvhLeafTarget + bvhLeafTol, bvhNodes,
+                                     bvhPrimIndices);
+        bvhDirty = false;
+    }
+
+    AABB boundingBox() const { // mesh.cuh:526-541
+        if (vertices.empty())
+            return {vec3(0.0f), vec3(0.0f)};
+        AABB b{vertices[0], vertices[0]};
+        for (size_t i = 1; i < vertices.size(); ++i)
+            b.expand(vertices[i]);
+        return b;
+    }
+
+    // vertex-baking transforms (mesh.cuh:548-640); each marks BVH + vertices dirty
+    void scale(float s) { scale(vec3(s)); }
+    void scale(vec3 s) {
+        for (auto &v : vertices) {
+            v.x *= s.x; v.y *= s.y; v.z *= s.z;
+        }
+        touch();
+    }
+    void translate(const vec3 &d) {
+        for (auto &v : vertices)
+            v = v + d;
+        touch();
+    }
+    void moveTo(const vec3 &p) {
+        AABB bb = boundingBox();
+        translate(p - (bb.bmin + bb.bmax) * 0.5f);
+    }
+    void rotateSelfEulerXYZ(const vec3 &rad) {
+        AABB bb = boundingBox();
+        const vec3 c = (bb.bmin + bb.bmax) * 0.5f;
+        const float cx = cosf(rad.x), sx = sinf(rad.x), cy = cosf(rad.y), sy = sinf(rad.y), cz = cosf(rad.z),
+                    sz = sinf(rad.z);
+        for (auto &v : vertices) {
+            vec3 p = v - c;
+            const float y1 = cx * p.y - sx * p.z, z1 = sx * p.y + cx * p.z; // about X
+            p.y = y1; p.z = z1;
+            const float x2 = cy * p.x + sy * p.z, z2 = -sy * p.x + cy * p.z; // about Y
+            p.x = x2; p.z = z2;
+            const float x3 = cz * p.x - sz * p.y, y3 = sz * p.x + cz * p.y; // about Z
+            p.x = x3; p.y = y3;
+            v = p + c;
+        }
+        touch();
+    }
+
+    // instance transform (mesh.cuh:165-197)
+    void setTransform(const Transform3D &t) { transform = t; transform.dirty = true; transform.updateMatrices(); }
+    void setPosition(const vec3 &p) { transform.setPosition(p); transform.updateMatrices(); }
+    void setRotation(const vec3 &r) { transform.setRotation(r); transform.updateMatrices(); }
+    void computeLocalAABB() { localAABB = boundingBox(); }
+    AABB getWorldAABB() const {
+        if (!transform.dirty && localAABB.bmin.x < 1e20f)
+            return transform.transformAABB(localAABB);
+        return boundingBox();
+    }
+
+  private:
+    void touch() { bvhDirty = true; vertsDirty = true; }
+};

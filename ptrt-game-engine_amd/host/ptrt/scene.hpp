@@ -1,0 +1,746 @@
+// ptrt/scene.hpp -- the host API of the PTRT path tracer, over the MI355X back end.
+//
+// `class Scene` keeps the reference's method names, defaults and error behaviour
+// (reference: src/pathtracer/scene/scene.cuh:78-2001) so a caller of the CUDA
+// renderer can switch headers.  What differs is underneath: the scene is
+// flattened once per change into plain arrays and handed to the C ABI of
+// include/ptrt.h, which owns every device allocation.  Out of scope here (see
+// DESIGN.md): denoiser, bloom, resolution scaling, HDRI sky, wireframe and
+// debug-visualisation helpers -- their setters are accepted and recorded so call
+// sites compile, and `render_to_device` reports when one is enabled.
+#pragma once
+#include "mesh.hpp"
+
+#include <cstdint>
+#include <iostream>
+#include <memory>
+#include <random>
+#include <string>
+#include <utility>
+#include <vector>
+
+// ---- Material (scene/material_lib.cuh:12-105) -----------------------------------------
+struct Material {
+    vec3 albedo{0.8f}, specular{0.04f};
+    float metallic = 0.0f, roughness = 0.5f;
+    vec3 emission{0.0f};
+    float ior = 1.5f, transmission = 0.0f, transmissionRoughness = 0.0f;
+    float clearcoat = 0.0f, clearcoatRoughness = 0.03f;
+    vec3 subsurfaceColor{1.0f};
+    float subsurfaceRadius = 0.0f, anisotropy = 0.0f, sheen = 0.0f;
+    vec3 sheenTint{0.5f};
+    float iridescence = 0.0f, iridescenceThickness = 550.0f;
+    Material() = default;
+    Material(const vec3 &alb, float rough = 0.5f, float met = 0.0f) {
+        albedo = alb;
+        roughness = rough;
+        metallic = met;
+        specular = lerp(vec3(0.04f), albedo, metallic);
+        transmissionRoughness = fmaxf(transmissionRoughness, roughness);
+    }
+};
+
+// ---- Light (scene/lights.cuh) ---------------------------------------------------------
+enum LightType { LIGHT_POINT = 0, LIGHT_DIRECTIONAL = 1, LIGHT_SPOT = 2 };
+struct Light {
+    LightType type = LIGHT_POINT;
+    vec3 position{0, 10, 0}, direction{0, -1, 0}, color{1.0f};
+    float intensity = 1.0f, range = 100.0f, innerCone = 0.5f, outerCone = 0.7f, radius = 0.0f;
+};
+
+// ---- Camera (scene/camera.cuh:32-205, ray-generation state only) ----------------------
+class Camera {
+    vec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+    float lens_radius = 0.0f, fov = 90.0f, aspect = 1.0f;
+
+    void rebuild(const vec3 &lookat, const vec3 &vup, float focus_dist) {
+        w = (origin - lookat).normalized();
+        u = cross(vup, w).normalized();
+        v = cross(w, u);
+        const float theta = fov * (PI / 180.0f);
+        const float h = tanf(theta / 2.0f);
+        const float viewport_height = 2.0f * h;
+        const float viewport_width = aspect * viewport_height;
+        horizontal = focus_dist * viewport_width * u;
+        vertical = focus_dist * viewport_height * v;
+        lower_left_corner = origin - horizontal * 0.5f - vertical * 0.5f - focus_dist * w;
+    }
+
+  public:
+    Camera(vec3 lookfrom, vec3 lookat, vec3 vup, float vfov, float aspect_ratio, float aperture = 0.0f,
+           float focus_dist = 1.0f, float = 0.1f, float = 1000.0f) {
+        origin = lookfrom;
+        fov = vfov;
+        aspect = aspect_ratio;
+        rebuild(lookat, vup, focus_dist);
+        lens_radius = aperture / 2.0f;
+    }
+    explicit Camera(float aspect_ratio, float viewport_height = 2.0f, float focal_length = 1.0f) {
+        origin = vec3(0.0f);
+        const float viewport_width = viewport_height * aspect_ratio;
+        horizontal = vec3(viewport_width, 0.0f, 0.0f);
+        vertical = vec3(0.0f, viewport_height, 0.0f);
+        lower_left_corner = origin - horizontal * 0.5f - vertical * 0.5f - vec3(0.0f, 0.0f, focal_length);
+        u = vec3(1, 0, 0);
+        v = vec3(0, 1, 0);
+        w = vec3(0, 0, 1);
+        aspect = aspect_ratio;
+    }
+    vec3 get_origin() const { return origin; }
+    vec3 get_lower_left_corner() const { return lower_left_corner; }
+    vec3 get_horizontal() const { return horizontal; }
+    vec3 get_vertical() const { return vertical; }
+    void set_position(const vec3 &pos) { // camera.cuh:271-299
+        vec3 old_center = lower_left_corner + 0.5f * horizontal + 0.5f * vertical;
+        float focus_dist = (origin - old_center).length();
+        vec3 lookat = origin - w * focus_dist;
+        vec3 vup = v;
+        origin = pos;
+        rebuild(lookat, vup, (origin - lookat).length());
+    }
+    void look_at(const vec3 &target, const vec3 &vup = vec3(0, 1, 0)) { // camera.cuh:306-331
+        rebuild(target, vup, (origin - target).length());
+    }
+    ptrt_camera flat() const {
+        auto c = [](const vec3 &a) { return ptrt_vec3{a.x, a.y, a.z}; };
+        return ptrt_camera{c(origin), c(lower_left_corner), c(horizontal), c(vertical), c(u), c(v), c(w), lens_radius};
+    }
+};
+
+// ---- blue-noise table (common/bluenoise.cuh:79-198) -----------------------------------
+// 64x64 jittered-stratified points relaxed by 25 rounds of O(N^2) toroidal
+// repulsion.  std::uniform_real_distribution<float> is implementation-defined;
+// the table this produces with libstdc++ is pinned in tests/golden/.
+struct BlueNoiseGenerator {
+    static std::vector<float> generateBlueNoise2D(int size, int relaxation_iterations) {
+        const int n = size * size;
+        std::vector<float> px(n), py(n), fx(n), fy(n);
+        std::mt19937 rng(12345);
+        std::uniform_real_distribution<float> dist(0.0f, 1.0f);
+        const float cell = 1.0f / size;
+        for (int y = 0; y < size; ++y)
+            for (int x = 0; x < size; ++x) {
+                const float jx = dist(rng); // x first, then y, one pair per point
+                const float jy = dist(rng);
+                px[y * size + x] = (x + jx) * cell;
+                py[y * size + x] = (y + jy) * cell;
+            }
+        const float step = 0.0001f, min_d2 = 0.0001f;
+        auto wrap = [](float a) {
+            float r = std::fmod(a, 1.0f);
+            return r < 0.0f ? r + 1.0f : r;
+        };
+        for (int it = 0; it < relaxation_iterations; ++it) {
+            for (int i = 0; i < n; ++i) {
+                float ax = 0.0f, ay = 0.0f;
+                const float xi = px[i], yi = py[i];
+                for (int j = 0; j < n; ++j) {
+                    if (i == j)
+                        continue;
+                    float dx = xi - px[j], dy = yi - py[j];
+                    if (dx > 0.5f) dx -= 1.0f;
+                    if (dx < -0.5f) dx += 1.0f;
+                    if (dy > 0.5f) dy -= 1.0f;
+                    if (dy < -0.5f) dy += 1.0f;
+                    float d2 = dx * dx + dy * dy;
+                    d2 = std::max(d2, min_d2);
+                    const float inv = 1.0f / d2;
+                    ax += dx * inv;
+                    ay += dy * inv;
+                }
+                fx[i] = ax;
+                fy[i] = ay;
+            }
+            for (int i = 0; i < n; ++i) {
+                const float mag = std::sqrt(fx[i] * fx[i] + fy[i] * fy[i]);
+                if (mag < 1e-6f)
+                    continue;
+                px[i] = wrap(px[i] + (fx[i] / mag) * step);
+                py[i] = wrap(py[i] + (fy[i] / mag) * step);
+            }
+        }
+        std::vector<float> out((size_t)n * 2);
+        for (int i = 0; i < n; ++i) {
+            out[i * 2] = px[i];
+            out[i * 2 + 1] = py[i];
+        }
+        return out;
+    }
+};
+// the table initBlueNoise() would upload (bluenoise.cuh:189-198), computed once per process
+inline const std::vector<float> &ptrtBlueNoiseTable() {
+    static const std::vector<float> t = BlueNoiseGenerator::generateBlueNoise2D(PTRT_BLUE_NOISE_SIZE, 25);
+    return t;
+}
+
+struct HitInfo { // math/intersection.cuh:108-124
+    bool hit = false;
+    float t = 1e30f;
+    vec3 point, normal;
+    int mesh_index = -1;
+    bool front_face = true;
+    float u = 0, v = 0;
+    int face_index = -1;
+    vec3 localPoint;
+};
+
+// ---- Scene ----------------------------------------------------------------------------
+class Scene {
+  public:
+    struct PerformanceSettings { // scene.cuh:189-199
+        bool enableDenoiser = true;
+        bool enableBloom = true;
+        bool enableMotionVectors = true;
+        int maxBounceDepth = 4;
+        int samplesPerPixel = 1;
+        float resolutionScale = 1.0f;
+        bool fastBVHUpdates = true;          // never read by the reference either
+        bool enableRussianRoulette = true;   // never read: RR always starts at bounce 2
+        int russianRouletteStartBounce = 1;  // never read (path_logic.cuh:24)
+    };
+
+    // Scene(w,h) of the reference; the extra arguments select a band of rows and a
+    // device for tile-parallel rendering and default to "whole frame,
+    // device 0".
+    Scene(int w, int h, int tile_y0 = 0, int tile_rows = 0, int device = 0)
+        : width(w), height(h), camera(static_cast<float>(w) / h, 2.0f, 1.0f) {
+        tileRows = tile_rows > 0 ? tile_rows : h;
+        if (device < 0)
+            return; // host-only scene: build/flatten/inspect, no back end (every GPU call then fails loudly)
+        int rc = ptrt_create(w, h, tile_y0, tile_rows, device, &ctx);
+        if (rc != PTRT_OK) {
+            std::string msg = std::string("Failed to create GPU context: ") + ptrt_last_error(ctx);
+            ptrt_destroy(ctx);
+            ctx = nullptr;
+            throw std::runtime_error(msg);
+        }
+        check(ptrt_reset_rng(ctx, PTRT_DEFAULT_SEED), "Failed to init rand states"); // scene.cuh:433-456
+    }
+    ~Scene() { ptrt_destroy(ctx); }
+    Scene(const Scene &) = delete;
+    Scene &operator=(const Scene &) = delete;
+
+    // the application's `initBlueNoise()` call; without it the table is all zeros,
+    // exactly as in the reference (bluenoise.cuh:46,189)
+    void initBlueNoise() { needBackend(); check(ptrt_set_blue_noise(ctx, ptrtBlueNoiseTable().data()), "blue noise upload failed"); }
+    void setBlueNoiseTable(const float *table) { needBackend(); check(ptrt_set_blue_noise(ctx, table), "blue noise upload failed"); }
+
+    // ---- accumulation / acceleration settings (scene.cuh:1270-1296) -----------------
+    void resetAccumulation() { frame_count_ = 0; }
+    void setBVHLeafTarget(int target, int tol = 5) {
+        bvhLeafTarget_ = target < 1 ? 1 : target;
+        bvhLeafTol_ = tol < 0 ? 0 : tol;
+        for (auto &m : meshes)
+            m->bvhDirty = true;
+        resetAccumulation();
+    }
+
+    // ---- camera (scene.cuh:1298-1331) -----------------------------------------------
+    void setCamera(const vec3 &lookfrom, const vec3 &lookat, const vec3 &vup, float vfov, float aperture = 0.0f,
+                   float focus_dist = 1.0f) {
+        camera = Camera(lookfrom, lookat, vup, vfov, static_cast<float>(width) / height, aperture, focus_dist);
+        cameraDirty = true;
+        resetAccumulation();
+    }
+    void setCameraSimple(float viewport_height = 2.0f, float focal_length = 1.0f) {
+        camera = Camera(static_cast<float>(width) / height, viewport_height, focal_length);
+        cameraDirty = true;
+        resetAccumulation();
+    }
+    vec3 cameraOrigin() const { return camera.get_origin(); }
+    vec3 cameraForward() const {
+        return (camera.get_lower_left_corner() + camera.get_horizontal() * 0.5f + camera.get_vertical() * 0.5f -
+                camera.get_origin())
+            .normalized();
+    }
+    void moveCamera(const vec3 &pos) { camera.set_position(pos); cameraDirty = true; resetAccumulation(); }
+    void lookCameraAt(const vec3 &target, const vec3 &vup = vec3(0, 1, 0)) {
+        camera.look_at(target, vup);
+        cameraDirty = true;
+        resetAccumulation();
+    }
+    Camera &getCamera() { cameraDirty = true; return camera; }
+
+    // ---- geometry (scene.cuh:1334-1500) ---------------------------------------------
+    Mesh *addMesh(const std::string &obj_path, const Material &mat = Material()) {
+        return push(std::make_unique<Mesh>(obj_path), mat);
+    }
+    Mesh *addTriangles(const std::vector<Triangle> &tris, const Material &mat = Material()) {
+        auto m = std::make_unique<Mesh>();
+        m->vertices.clear();
+        m->faces.clear();
+        m->vertices.reserve(tris.size() * 3);
+        m->faces.reserve(tris.size());
+        for (const Triangle &t : tris) {
+            const int base = (int)m->vertices.size();
+            m->vertices.push_back(t.v0);
+            m->vertices.push_back(t.v1);
+            m->vertices.push_back(t.v2);
+            m->faces.push_back(Tri{base, base + 1, base + 2});
+        }
+        return push(std::move(m), mat);
+    }
+    Mesh *addPlaneXZ(float planeY, float halfSize, const Material &mat = Material(vec3(0.8f))) {
+        const vec3 A(-halfSize, planeY, -halfSize), B(halfSize, planeY, -halfSize), C(halfSize, planeY, halfSize),
+            D(-halfSize, planeY, halfSize);
+        return addTriangles({Triangle(A, C, B), Triangle(A, D, C)}, mat); // CCW from +Y
+    }
+    void addCheckerboardPlaneXZ(float planeY, int tilesPerSide, float tileSize, const Material &whiteMat,
+                                const Material &blackMat) {
+        std::vector<Triangle> white, black;
+        const int N = tilesPerSide;
+        const float start = -N * tileSize;
+        for (int iz = 0; iz < 2 * N; ++iz)
+            for (int ix = 0; ix < 2 * N; ++ix) {
+                const float x0 = start + ix * tileSize, x1 = x0 + tileSize;
+                const float z0 = start + iz * tileSize, z1 = z0 + tileSize;
+                const vec3 A(x0, planeY, z0), B(x1, planeY, z0), C(x1, planeY, z1), D(x0, planeY, z1);
+                auto &bucket = (((ix + iz) & 1) == 0) ? white : black;
+                bucket.emplace_back(A, C, B);
+                bucket.emplace_back(A, D, C);
+            }
+        if (!white.empty())
+            addTriangles(white, whiteMat);
+        if (!black.empty())
+            addTriangles(black, blackMat);
+    }
+    Mesh *addCube(const Material &mat = Material(vec3(1.0f, 0.0f, 0.0f))) { return push(std::make_unique<Mesh>(), mat); }
+    // UV sphere of diameter 1: (segments+1)^2 vertices, 2*segments^2 faces (scene.cuh:1455-1500)
+    Mesh *addSphere(int segments = 32, const Material &mat = Material(vec3(1.0f, 0.0f, 0.0f))) {
+        auto m = std::make_unique<Mesh>();
+        m->vertices.clear();
+        m->faces.clear();
+        const int rings = segments, sectors = segments;
+        const float radius = 0.5f;
+        for (int r = 0; r <= rings; ++r) {
+            const float phi = PI * float(r) / float(rings);
+            const float y = cosf(phi) * radius;
+            const float ringRadius = sinf(phi) * radius;
+            for (int s = 0; s <= sectors; ++s) {
+                const float theta = TWO_PI * float(s) / float(sectors);
+                m->vertices.push_back(vec3(ringRadius * cosf(theta), y, ringRadius * sinf(theta)));
+            }
+        }
+        for (int r = 0; r < rings; ++r)
+            for (int s = 0; s < sectors; ++s) {
+                const int curr = r * (sectors + 1) + s, next = curr + sectors + 1;
+                m->faces.push_back({curr, next, curr + 1});
+                m->faces.push_back({curr + 1, next, next + 1});
+            }
+        return push(std::move(m), mat);
+    }
+
+    // ---- lights (scene.cuh:1503-1545, 1800-1827) -------------------------------------
+    void addPointLight(const vec3 &position, const vec3 &color, float intensity = 1.0f, float range = 100.0f,
+                       float radius = 0.0f) {
+        Light l;
+        l.type = LIGHT_POINT;
+        l.position = position;
+        l.color = color;
+        l.intensity = intensity;
+        l.range = range;
+        l.radius = radius;
+        addLight(l);
+    }
+    void addDirectionalLight(const vec3 &direction, const vec3 &color, float intensity = 1.0f) {
+        Light l;
+        l.type = LIGHT_DIRECTIONAL;
+        l.direction = direction.normalized();
+        l.color = color;
+        l.intensity = intensity;
+        addLight(l);
+    }
+    // cone angles are given in radians and stored as cosines
+    void addSpotLight(const vec3 &position, const vec3 &direction, const vec3 &color, float intensity = 1.0f,
+                      float innerCone = 0.5f, float outerCone = 0.7f, float range = 100.0f, float radius = 0.0f) {
+        Light l;
+        l.type = LIGHT_SPOT;
+        l.position = position;
+        l.direction = direction.normalized();
+        l.color = color;
+        l.intensity = intensity;
+        l.innerCone = cosf(innerCone);
+        l.outerCone = cosf(outerCone);
+        l.range = range;
+        l.radius = radius;
+        addLight(l);
+    }
+    Light *getLight(size_t i) { return i < lights.size() ? &lights[i] : nullptr; }
+    size_t getLightCount() const { return lights.size(); }
+    void moveLightTo(size_t i, const vec3 &position) {
+        if (Light *l = getLight(i)) {
+            l->position = position;
+            lightsDirty = true;
+            resetAccumulation();
+        }
+    }
+    void commitLightChanges() {
+        if (!lights.empty()) {
+            lightsDirty = true;
+            resetAccumulation();
+        }
+    }
+
+    // ---- sky (scene.cuh:1548-1565) ---------------------------------------------------
+    void setSkyGradient(const vec3 &top, const vec3 &bottom) {
+        sky_color_top = top;
+        sky_color_bottom = bottom;
+        use_sky = true;
+        skyDirty = true;
+        resetAccumulation();
+    }
+    void disableSky() { use_sky = false; skyDirty = true; resetAccumulation(); }
+
+    // ---- materials / objects ---------------------------------------------------------
+    void setMeshMaterial(size_t index, const Material &mat) {
+        if (index < mesh_materials.size())
+            mesh_materials[index] = mat;
+    }
+    void commitMaterialChanges() { materialsDirty = true; resetAccumulation(); }
+    Mesh *getMesh(size_t i) { return i < meshes.size() ? meshes[i].get() : nullptr; }
+    const Mesh *getMesh(size_t i) const { return i < meshes.size() ? meshes[i].get() : nullptr; }
+    size_t getMeshCount() const { return meshes.size(); }
+    void moveMeshTo(size_t i, const vec3 &p) { if (Mesh *m = getMesh(i)) m->moveTo(p); }
+    void translateMesh(size_t i, const vec3 &d) { if (Mesh *m = getMesh(i)) m->translate(d); }
+    void rotateMesh(size_t i, const vec3 &r) { if (Mesh *m = getMesh(i)) m->rotateSelfEulerXYZ(r); }
+    void scaleMesh(size_t i, float s) { if (Mesh *m = getMesh(i)) m->scale(s); }
+    void scaleMesh(size_t i, const vec3 &s) { if (Mesh *m = getMesh(i)) m->scale(s); }
+    void commitObjectChanges() { updateAccelerationStructures(); resetAccumulation(); } // scene.cuh:1784
+    bool hasObjectChanges() const {
+        for (auto &m : meshes)
+            if (m->bvhDirty)
+                return true;
+        return false;
+    }
+
+    // ---- quality knobs (scene.cuh:1833-1912) -----------------------------------------
+    void setPerformancePreset(const std::string &p) {
+        auto set = [&](bool dn, bool bl, bool mv, int depth, float scale, int rr) {
+            perfSettings.enableDenoiser = dn;
+            perfSettings.enableBloom = bl;
+            perfSettings.enableMotionVectors = mv;
+            perfSettings.maxBounceDepth = depth;
+            perfSettings.resolutionScale = scale;
+            perfSettings.russianRouletteStartBounce = rr;
+        };
+        if (p == "ultra") { set(false, true, true, 32, 1.0f, 8); perfSettings.samplesPerPixel = 128; }
+        else if (p == "quality") set(true, true, true, 6, 1.0f, 2);
+        else if (p == "balanced") set(true, true, true, 4, 1.0f, 1);
+        else if (p == "performance") set(true, false, true, 3, 0.75f, 1);
+        else if (p == "fast") set(false, false, false, 2, 0.35f, 1);
+    }
+    void setDenoiserEnabled(bool e) { perfSettings.enableDenoiser = e; }
+    void setBloomEnabled(bool e) { perfSettings.enableBloom = e; }
+    void setMaxBounceDepth(int d) { perfSettings.maxBounceDepth = d < 1 ? 1 : (d > 16 ? 16 : d); }
+    void setResolutionScale(float s) {
+        s = fmaxf(0.25f, fminf(1.0f, s));
+        if (fabsf(s - perfSettings.resolutionScale) > 0.01f)
+            perfSettings.resolutionScale = s;
+    }
+    // not in the reference (its samplesPerPixel is only reachable through the
+    // "ultra" preset); needed to express the 4-spp benchmark configurations
+    void setSamplesPerPixel(int spp) { perfSettings.samplesPerPixel = spp < 1 ? 1 : spp; }
+    const PerformanceSettings &getPerformanceSettings() const { return perfSettings; }
+
+    // ---- upload + render -------------------------------------------------------------
+    void uploadToGPU() { // scene.cuh:1643-1657
+        if (meshes.empty()) {
+            std::cerr << "Warning: No meshes in scene\n";
+            return;
+        }
+        if (meshes.size() != mesh_materials.size())
+            throw std::runtime_error("Mesh count and material count mismatch!");
+        updateAccelerationStructures();
+        gpu_resources_initialized = true;
+        resetAccumulation();
+    }
+
+    // One frame: acceleration-structure update, path trace, tonemap into
+    // `device_pixels` (W*rows*3 bytes on the device, bottom-up).  Returns without
+    // synchronising, like the reference (scene.cuh:1028-1209).
+    void render_to_device(unsigned char *device_pixels) { renderInternal(device_pixels, 1); }
+    // same frame into HOST memory (synchronous); the reference has no such call on
+    // its PT Scene -- callers there map a GL buffer instead
+    void render_to_host(unsigned char *host_pixels) { renderInternal(host_pixels, 0); }
+
+    HitInfo traceSingleRay(const vec3 &o, const vec3 &d) { // scene.cuh:1367-1391
+        HitInfo h;
+        needBackend();
+        float of[3] = {o.x, o.y, o.z}, df[3] = {d.x, d.y, d.z};
+        ptrt_hit r;
+        if (ptrt_trace_rays(ctx, of, df, 1, &r) != PTRT_OK) {
+            std::cerr << "traceSingleRay failed: " << ptrt_last_error(ctx) << "\n";
+            return h;
+        }
+        h.hit = r.hit != 0;
+        h.t = r.t;
+        h.point = vec3(r.point.x, r.point.y, r.point.z);
+        h.normal = vec3(r.normal.x, r.normal.y, r.normal.z);
+        h.mesh_index = r.mesh_index;
+        h.front_face = r.front_face != 0;
+        h.u = r.u;
+        h.v = r.v;
+        h.face_index = r.face_index;
+        h.localPoint = vec3(r.local_point.x, r.local_point.y, r.local_point.z);
+        return h;
+    }
+
+    void saveAsPPM(const std::string &filename, unsigned char *pixels) const { // ASCII P3, scene.cuh:1694-1708
+        std::ofstream ofs(filename, std::ios::binary);
+        if (!ofs)
+            throw std::runtime_error("Cannot open file: " + filename);
+        ofs << "P3\n" << width << ' ' << height << "\n255\n";
+        for (size_t i = 0, n = (size_t)width * height * 3; i < n; i += 3)
+            ofs << int(pixels[i]) << ' ' << int(pixels[i + 1]) << ' ' << int(pixels[i + 2]) << '\n';
+    }
+
+    int getWidth() const { return width; }
+    int getHeight() const { return height; }
+    size_t getPixelBufferSize() const { return (size_t)width * height * 3; }
+    int getFrameCount() const { return frame_count_; }
+    // DEVICE pointers, as in the reference (scene.cuh:1722-1725)
+    vec3 *getNoisyColorBuffer() { return (vec3 *)ptrt_device_buffer(ctx, PTRT_BUF_ACCUM); }
+    vec3 *getNormalBuffer() { return (vec3 *)ptrt_device_buffer(ctx, PTRT_BUF_NORMAL); }
+    float *getDepthBuffer() { return (float *)ptrt_device_buffer(ctx, PTRT_BUF_DEPTH); }
+    int *getObjectIdBuffer() { return (int *)ptrt_device_buffer(ctx, PTRT_BUF_OBJECT_ID); }
+
+    // ---- access for tests, tools and the tile farm -----------------------------------
+    ptrt_ctx *backend() { return ctx; }
+    void setFrameCount(int f) { frame_count_ = f; }
+    // Flattened view of the current scene (pointers stay valid until the next
+    // mutation of the scene).  Brings BLAS/TLAS up to date first.
+    const ptrt_scene_desc &flatten() {
+        prepareHostStructures();
+        return flat;
+    }
+
+  private:
+    int width, height, tileRows = 0;
+    int frame_count_ = 0;
+    int bvhLeafTarget_ = 12, bvhLeafTol_ = 5; // scene.cuh:90-91
+    std::vector<std::unique_ptr<Mesh>> meshes;
+    std::vector<Material> mesh_materials;
+    std::vector<Light> lights;
+    Camera camera;
+    bool use_sky = true;
+    vec3 sky_color_top{0.6f, 0.7f, 1.0f}, sky_color_bottom{1.0f, 1.0f, 1.0f}; // scene.cuh:164-166
+    PerformanceSettings perfSettings;
+    bool gpu_resources_initialized = false;
+
+    ptrt_ctx *ctx = nullptr;
+    bool geometryDirty = true, materialsDirty = true, lightsDirty = true, cameraDirty = true, skyDirty = true;
+    bool warnedPost = false;
+
+    // flattened arrays handed to the back end
+    std::vector<ptrt_mesh_desc> flatMeshes;
+    std::vector<mat4> lastWorld;
+    std::vector<DeviceBVHNode> h_tlasNodes;
+    std::vector<int> h_tlasMeshIndices;
+    std::vector<ptrt_light> flatLights;
+    struct MatSoA {
+        std::vector<ptrt_vec3> albedo, specular, emission, subsurfaceColor, sheenTint;
+        std::vector<float> metallic, roughness, ior, transmission, transmissionRoughness, clearcoat,
+            clearcoatRoughness, subsurfaceRadius, anisotropy, sheen, iridescence, iridescenceThickness;
+    } soa;
+    ptrt_scene_desc flat{};
+
+    void needBackend() const {
+        if (!ctx)
+            throw std::runtime_error("host-only Scene (device < 0) has no GPU back end");
+    }
+    void check(int rc, const char *what) {
+        if (rc != PTRT_OK)
+            throw std::runtime_error(std::string(what) + ": " + ptrt_last_error(ctx));
+    }
+    Mesh *push(std::unique_ptr<Mesh> m, const Material &mat) {
+        meshes.push_back(std::move(m));
+        mesh_materials.push_back(mat);
+        geometryDirty = materialsDirty = true;
+        resetAccumulation();
+        return meshes.back().get();
+    }
+    void addLight(const Light &l) {
+        lights.push_back(l);
+        lightsDirty = true;
+        resetAccumulation();
+    }
+
+    // TLAS over the meshes' world AABBs, same builder and leaf limit as the BLAS
+    // (scene.cuh:458-594)
+    void buildTLAS() {
+        std::vector<ptrt_detail::BuildRef> refs(meshes.size());
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            Mesh *m = meshes[i].get();
+            if (m->transform.dirty)
+                m->transform.updateMatrices();
+            if (m->bvhNodes.empty())
+                throw std::runtime_error("Mesh BVH not built before TLAS");
+            const DeviceBVHNode &root = m->bvhNodes[0];
+            AABB local{vec3(root.bmin.x, root.bmin.y, root.bmin.z), vec3(root.bmax.x, root.bmax.y, root.bmax.z)};
+            AABB world = m->transform.transformAABB(local);
+            refs[i].id = (int)i;
+            refs[i].b = world;
+            refs[i].c = world.center();
+        }
+        h_tlasNodes.clear();
+        h_tlasMeshIndices.clear();
+        ptrt_detail::build_bvh_range(refs, 0, (int)refs.size(), bvhLeafTarget_ + bvhLeafTol_, h_tlasNodes,
+                                     h_tlasMeshIndices);
+    }
+
+    // host half of updateAccelerationStructures (scene.cuh:596-743): rebuild dirty
+    // BLAS, refresh descriptors, detect moved instances, rebuild the TLAS
+    void prepareHostStructures() {
+        if (meshes.empty())
+            return;
+        bool tlas_dirty = h_tlasNodes.empty();
+        if (flatMeshes.size() != meshes.size()) {
+            flatMeshes.assign(meshes.size(), ptrt_mesh_desc{});
+            lastWorld.assign(meshes.size(), mat4());
+            tlas_dirty = true;
+            geometryDirty = materialsDirty = true;
+        }
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            Mesh *m = meshes[i].get();
+            if (m->vertsDirty) {
+                geometryDirty = true;
+                m->vertsDirty = false;
+            }
+            if (m->bvhDirty || m->bvhNodes.empty()) {
+                m->setBVHLeafParams(bvhLeafTarget_, bvhLeafTol_);
+                m->buildBVH();
+                tlas_dirty = true;
+                geometryDirty = true;
+            }
+            bool moved = m->transform.dirty;
+            if (moved)
+                m->transform.updateMatrices();
+            else
+                moved = std::memcmp(&lastWorld[i], &m->transform.worldMatrix, sizeof(mat4)) != 0;
+            if (moved) {
+                tlas_dirty = true;
+                geometryDirty = true;
+            }
+            lastWorld[i] = m->transform.worldMatrix;
+            ptrt_mesh_desc &d = flatMeshes[i];
+            d.verts = reinterpret_cast<const ptrt_vec3 *>(m->vertices.data());
+            d.vert_count = (int)m->vertices.size();
+            d.faces = m->faces.data();
+            d.face_count = (int)m->faces.size();
+            d.nodes = m->bvhNodes.data();
+            d.node_count = (int)m->bvhNodes.size();
+            d.prim_indices = m->bvhPrimIndices.data();
+            d.prim_count = (int)m->bvhPrimIndices.size();
+            std::memcpy(d.world, m->transform.worldMatrix.m, sizeof d.world);
+            std::memcpy(d.inverse, m->transform.inverseMatrix.m, sizeof d.inverse);
+            std::memcpy(d.normal, m->transform.normalMatrix.m, sizeof d.normal);
+            d.has_transform = (m->transform.position.length() > 0.001f || m->transform.rotation.length() > 0.001f ||
+                               fabsf(m->transform.scale.x - 1.0f) > 0.001f)
+                                  ? 1
+                                  : 0; // scene.cuh:718-721 (only scale.x is inspected)
+        }
+        if (tlas_dirty)
+            buildTLAS();
+
+        // materials: AoS -> SoA (scene.cuh:286-431)
+        const size_t n = mesh_materials.size();
+        auto c = [](const vec3 &a) { return ptrt_vec3{a.x, a.y, a.z}; };
+        soa.albedo.resize(n); soa.specular.resize(n); soa.emission.resize(n); soa.subsurfaceColor.resize(n);
+        soa.sheenTint.resize(n); soa.metallic.resize(n); soa.roughness.resize(n); soa.ior.resize(n);
+        soa.transmission.resize(n); soa.transmissionRoughness.resize(n); soa.clearcoat.resize(n);
+        soa.clearcoatRoughness.resize(n); soa.subsurfaceRadius.resize(n); soa.anisotropy.resize(n);
+        soa.sheen.resize(n); soa.iridescence.resize(n); soa.iridescenceThickness.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Material &m = mesh_materials[i];
+            soa.albedo[i] = c(m.albedo); soa.specular[i] = c(m.specular); soa.emission[i] = c(m.emission);
+            soa.subsurfaceColor[i] = c(m.subsurfaceColor); soa.sheenTint[i] = c(m.sheenTint);
+            soa.metallic[i] = m.metallic; soa.roughness[i] = m.roughness; soa.ior[i] = m.ior;
+            soa.transmission[i] = m.transmission; soa.transmissionRoughness[i] = m.transmissionRoughness;
+            soa.clearcoat[i] = m.clearcoat; soa.clearcoatRoughness[i] = m.clearcoatRoughness;
+            soa.subsurfaceRadius[i] = m.subsurfaceRadius; soa.anisotropy[i] = m.anisotropy; soa.sheen[i] = m.sheen;
+            soa.iridescence[i] = m.iridescence; soa.iridescenceThickness[i] = m.iridescenceThickness;
+        }
+        flatLights.resize(lights.size());
+        for (size_t i = 0; i < lights.size(); ++i) {
+            const Light &l = lights[i];
+            flatLights[i] = ptrt_light{(int32_t)l.type, c(l.position), c(l.direction), c(l.color), l.intensity,
+                                       l.range, l.innerCone, l.outerCone, l.radius};
+        }
+        flat.meshes = flatMeshes.data();
+        flat.mesh_count = (int)flatMeshes.size();
+        flat.tlas_nodes = h_tlasNodes.data();
+        flat.tlas_node_count = (int)h_tlasNodes.size();
+        flat.tlas_mesh_indices = h_tlasMeshIndices.data();
+        flat.tlas_index_count = (int)h_tlasMeshIndices.size();
+        flat.materials = ptrt_materials{soa.albedo.data(), soa.specular.data(), soa.metallic.data(),
+                                        soa.roughness.data(), soa.emission.data(), soa.ior.data(),
+                                        soa.transmission.data(), soa.transmissionRoughness.data(),
+                                        soa.clearcoat.data(), soa.clearcoatRoughness.data(),
+                                        soa.subsurfaceColor.data(), soa.subsurfaceRadius.data(),
+                                        soa.anisotropy.data(), soa.sheen.data(), soa.sheenTint.data(),
+                                        soa.iridescence.data(), soa.iridescenceThickness.data(), (int32_t)n};
+        flat.lights = flatLights.data();
+        flat.light_count = (int)flatLights.size();
+        flat.camera = camera.flat();
+        flat.sky_top = c(sky_color_top);
+        flat.sky_bottom = c(sky_color_bottom);
+        flat.use_sky = use_sky ? 1 : 0;
+    }
+
+    void updateAccelerationStructures() {
+        if (meshes.empty())
+            return;
+        needBackend();
+        prepareHostStructures();
+        if (geometryDirty) {
+            check(ptrt_upload_geometry(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,
+                                       flat.tlas_mesh_indices, flat.tlas_index_count),
+                  "Failed to upload geometry");
+            geometryDirty = false;
+        }
+        if (materialsDirty) {
+            check(ptrt_upload_materials(ctx, &flat.materials), "Failed to upload materials");
+            materialsDirty = false;
+        }
+        if (lightsDirty) {
+            check(ptrt_upload_lights(ctx, flat.lights, flat.light_count), "Failed to upload lights");
+            lightsDirty = false;
+        }
+        gpu_resources_initialized = true;
+    }
+
+    void renderInternal(unsigned char *pixels, int is_device) {
+        // validateGPUResources: message on cerr and return without rendering (scene.cuh:216-251,1029-1031)
+        if (meshes.empty()) {
+            std::cerr << "ERROR: No meshes in scene!\n";
+            return;
+        }
+        if (!gpu_resources_initialized) {
+            std::cerr << "ERROR: Mesh descriptors not allocated!\n";
+            return;
+        }
+        if ((perfSettings.enableDenoiser || perfSettings.enableBloom || perfSettings.resolutionScale != 1.0f) &&
+            !warnedPost) {
+            std::cerr << "NOTE: denoiser/bloom/resolution scaling are not part of this back end; "
+                         "rendering the raw path-traced frame\n";
+            warnedPost = true;
+        }
+        updateAccelerationStructures();
+        if (cameraDirty) {
+            ptrt_camera c = camera.flat();
+            check(ptrt_set_camera(ctx, &c), "Failed to set camera");
+            cameraDirty = false;
+        }
+        if (skyDirty) {
+            ptrt_vec3 t{sky_color_top.x, sky_color_top.y, sky_color_top.z},
+                b{sky_color_bottom.x, sky_color_bottom.y, sky_color_bottom.z};
+            check(ptrt_set_sky(ctx, &t, &b, use_sky ? 1 : 0), "Failed to set sky");
+            skyDirty = false;
+        }
+        int rc = ptrt_render(ctx, frame_count_, perfSettings.samplesPerPixel, perfSettings.maxBounceDepth, pixels,
+                             is_device);
+        if (rc != PTRT_OK) // launch errors are logged, not thrown (scene.cuh:1036-1042)
+            std::cerr << "HIP kernel launch failed at path_trace_kernel: " << ptrt_last_error(ctx) << "\n";
+        frame_count_++;
+    }
+};

@@ -1,0 +1,406 @@
+"""ptrt_amd -- Python (ctypes) binding of libptrt_amd.so.
+
+Two layers, both plain C underneath:
+  * the C ABI of include/ptrt.h (``lib.ptrt_*``): the drop-in boundary of the
+    MI355X path-tracing back end;
+  * ``Scene``: the reference's host API (``class Scene`` of
+    src/pathtracer/scene/scene.cuh:78-2001) as implemented by the C++ mirror in
+    host/ptrt/scene.hpp, reached through its flat ``hs_*`` entry points.
+
+Nothing here computes pixels: if the shared library is missing the import fails,
+and if there is no HIP device ``Scene(..., device>=0)`` raises.  A ``device=-1``
+scene is host-only (build / flatten / inspect) and cannot render.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptrt_amd.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C ptrt-game-engine_amd` "
+        "(or __graft_entry__.build()); there is no fallback implementation"
+    )
+lib = C.CDLL(LIB_PATH)
+
+PTRT_OK = 0
+BUF_ACCUM, BUF_NORMAL, BUF_DEPTH, BUF_OBJECT_ID, BUF_RGB8, BUF_RNG = range(6)
+DEFAULT_SEED = 12345
+HOST_ONLY = -1
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bmin", Vec3), ("bmax", Vec3), ("left", C.c_int32), ("right", C.c_int32),
+                ("start", C.c_int32), ("count", C.c_int32)]
+
+
+class Tri(C.Structure):
+    _fields_ = [("v0", C.c_int32), ("v1", C.c_int32), ("v2", C.c_int32)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("verts", C.POINTER(Vec3)), ("vert_count", C.c_int32),
+                ("faces", C.POINTER(Tri)), ("face_count", C.c_int32),
+                ("nodes", C.POINTER(BvhNode)), ("node_count", C.c_int32),
+                ("prim_indices", C.POINTER(C.c_int32)), ("prim_count", C.c_int32),
+                ("world", C.c_float * 16), ("inverse", C.c_float * 16), ("normal", C.c_float * 16),
+                ("has_transform", C.c_int32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("position", Vec3), ("direction", Vec3), ("color", Vec3),
+                ("intensity", C.c_float), ("range", C.c_float), ("inner_cone", C.c_float),
+                ("outer_cone", C.c_float), ("radius", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", Vec3), ("lower_left_corner", Vec3), ("horizontal", Vec3), ("vertical", Vec3),
+                ("u", Vec3), ("v", Vec3), ("w", Vec3), ("lens_radius", C.c_float)]
+
+
+_MAT_FIELDS = ["albedo", "specular", "metallic", "roughness", "emission", "ior", "transmission",
+               "transmission_roughness", "clearcoat", "clearcoat_roughness", "subsurface_color",
+               "subsurface_radius", "anisotropy", "sheen", "sheen_tint", "iridescence",
+               "iridescence_thickness"]
+_MAT_VEC = {"albedo", "specular", "emission", "subsurface_color", "sheen_tint"}
+
+
+class Materials(C.Structure):
+    _fields_ = [(n, C.POINTER(Vec3) if n in _MAT_VEC else C.POINTER(C.c_float)) for n in _MAT_FIELDS] + \
+               [("count", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("meshes", C.POINTER(MeshDesc)), ("mesh_count", C.c_int32),
+                ("tlas_nodes", C.POINTER(BvhNode)), ("tlas_node_count", C.c_int32),
+                ("tlas_mesh_indices", C.POINTER(C.c_int32)), ("tlas_index_count", C.c_int32),
+                ("materials", Materials),
+                ("lights", C.POINTER(Light)), ("light_count", C.c_int32),
+                ("camera", Camera), ("sky_top", Vec3), ("sky_bottom", Vec3), ("use_sky", C.c_int32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("hit", C.c_int32), ("t", C.c_float), ("point", Vec3), ("normal", Vec3),
+                ("mesh_index", C.c_int32), ("front_face", C.c_int32), ("u", C.c_float), ("v", C.c_float),
+                ("face_index", C.c_int32), ("local_point", Vec3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64)]
+
+
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3),
+                      ("mesh_index", "<i4"), ("front_face", "<i4"), ("u", "<f4"), ("v", "<f4"),
+                      ("face_index", "<i4"), ("local_point", "<f4", 3)])
+assert HIT_DTYPE.itemsize == C.sizeof(Hit) == 64
+
+_vp = C.c_void_p
+_fp = C.POINTER(C.c_float)
+
+
+def _sig(name, res, *args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = list(args)
+    return f
+
+
+# ---- include/ptrt.h ------------------------------------------------------------------
+_sig("ptrt_abi_version", C.c_int)
+_sig("ptrt_last_error", C.c_char_p, _vp)
+_sig("ptrt_create", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp))
+_sig("ptrt_destroy", None, _vp)
+_sig("ptrt_set_blue_noise", C.c_int, _vp, _fp)
+_sig("ptrt_reset_rng", C.c_int, _vp, C.c_ulonglong)
+_sig("ptrt_upload_geometry", C.c_int, _vp, C.POINTER(MeshDesc), C.c_int, C.POINTER(BvhNode), C.c_int,
+     C.POINTER(C.c_int32), C.c_int)
+_sig("ptrt_upload_materials", C.c_int, _vp, C.POINTER(Materials))
+_sig("ptrt_upload_lights", C.c_int, _vp, C.POINTER(Light), C.c_int)
+_sig("ptrt_set_camera", C.c_int, _vp, C.POINTER(Camera))
+_sig("ptrt_set_sky", C.c_int, _vp, C.POINTER(Vec3), C.POINTER(Vec3), C.c_int)
+_sig("ptrt_upload_scene", C.c_int, _vp, C.POINTER(SceneDesc))
+_sig("ptrt_render", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int)
+_sig("ptrt_sync", C.c_int, _vp)
+_sig("ptrt_read_buffer", C.c_int, _vp, C.c_int, _vp, C.c_size_t)
+_sig("ptrt_device_buffer", _vp, _vp, C.c_int)
+_sig("ptrt_write_rng", C.c_int, _vp, C.POINTER(C.c_uint32), C.c_size_t)
+_sig("ptrt_trace_rays", C.c_int, _vp, _fp, _fp, C.c_int, _vp)
+_sig("ptrt_get_stats", C.c_int, _vp, C.POINTER(Stats))
+_sig("ptrt_set_option", C.c_int, _vp, C.c_char_p, C.c_longlong)
+_sig("ptrt_last_kernel_ms", C.c_int, _vp, _fp, _fp)
+_sig("ptrt_debug_detmath", C.c_int, _vp, C.c_int, _fp, _fp, C.c_int, _fp)
+
+# ---- Scene mirror (csrc/ptrt_host_capi.cpp) ---------------------------------------------
+_sig("hs_last_error", C.c_char_p)
+_sig("hs_material_default", None, _fp)
+_sig("hs_material_make", None, _fp, C.c_float, C.c_float, _fp)
+_sig("hs_scene_create", _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("hs_scene_destroy", None, _vp)
+_sig("hs_backend", _vp, _vp)
+_sig("hs_init_blue_noise", C.c_int, _vp)
+_sig("hs_blue_noise_table", None, _fp)
+_sig("hs_blue_noise_generate", None, C.c_int, C.c_int, _fp)
+_sig("hs_add_cube", C.c_int, _vp, _fp)
+_sig("hs_add_sphere", C.c_int, _vp, C.c_int, _fp)
+_sig("hs_add_plane_xz", C.c_int, _vp, C.c_float, C.c_float, _fp)
+_sig("hs_add_triangles", C.c_int, _vp, _fp, C.c_int, _fp)
+_sig("hs_add_mesh_obj", C.c_int, _vp, C.c_char_p, _fp)
+_sig("hs_add_checkerboard", C.c_int, _vp, C.c_float, C.c_int, C.c_float, _fp, _fp)
+_sig("hs_mesh_op", C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float)
+_sig("hs_mesh_set_vertices", C.c_int, _vp, C.c_int, _fp, C.c_int)
+_sig("hs_mesh_counts", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
+_sig("hs_add_point_light", None, _vp, _fp, _fp, C.c_float, C.c_float, C.c_float)
+_sig("hs_add_directional_light", None, _vp, _fp, _fp, C.c_float)
+_sig("hs_add_spot_light", None, _vp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float)
+_sig("hs_move_light_to", None, _vp, C.c_int, _fp)
+_sig("hs_set_camera", None, _vp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float)
+_sig("hs_move_camera", None, _vp, _fp)
+_sig("hs_look_camera_at", None, _vp, _fp)
+_sig("hs_set_sky_gradient", None, _vp, _fp, _fp)
+_sig("hs_disable_sky", None, _vp)
+_sig("hs_set_bvh_leaf_target", None, _vp, C.c_int, C.c_int)
+_sig("hs_set_max_bounce_depth", None, _vp, C.c_int)
+_sig("hs_set_samples_per_pixel", None, _vp, C.c_int)
+_sig("hs_set_denoiser_enabled", None, _vp, C.c_int)
+_sig("hs_set_bloom_enabled", None, _vp, C.c_int)
+_sig("hs_set_performance_preset", None, _vp, C.c_char_p)
+_sig("hs_get_settings", None, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+     C.POINTER(C.c_int), _fp)
+_sig("hs_set_mesh_material", C.c_int, _vp, C.c_int, _fp)
+_sig("hs_upload", C.c_int, _vp)
+_sig("hs_commit_object_changes", C.c_int, _vp)
+_sig("hs_render_to_device", C.c_int, _vp, _vp)
+_sig("hs_render_to_host", C.c_int, _vp, _vp)
+_sig("hs_get_frame_count", C.c_int, _vp)
+_sig("hs_set_frame_count", None, _vp, C.c_int)
+_sig("hs_trace_single_ray", C.c_int, _vp, _fp, _fp, C.POINTER(Hit))
+_sig("hs_save_ppm", C.c_int, _vp, C.c_char_p, _vp)
+_sig("hs_flatten", C.POINTER(SceneDesc), _vp)
+
+
+class PtrtError(RuntimeError):
+    pass
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(a) for a in v])
+
+
+def _fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+class Material:
+    """`struct Material` (scene/material_lib.cuh:12-105) as 27 floats."""
+    NAMES = {"albedo": (0, 3), "specular": (3, 3), "metallic": (6, 1), "roughness": (7, 1), "emission": (8, 3),
+             "ior": (11, 1), "transmission": (12, 1), "transmissionRoughness": (13, 1), "clearcoat": (14, 1),
+             "clearcoatRoughness": (15, 1), "subsurfaceColor": (16, 3), "subsurfaceRadius": (19, 1),
+             "anisotropy": (20, 1), "sheen": (21, 1), "sheenTint": (22, 3), "iridescence": (25, 1),
+             "iridescenceThickness": (26, 1)}
+
+    def __init__(self, albedo=None, roughness=0.5, metallic=0.0, **fields):
+        self.f = np.zeros(27, dtype=np.float32)
+        if albedo is None:
+            lib.hs_material_default(_fptr(self.f))
+        else:
+            lib.hs_material_make(_f3(albedo), float(roughness), float(metallic), _fptr(self.f))
+        for k, v in fields.items():
+            self.set(k, v)
+
+    def set(self, name, value):
+        off, n = self.NAMES[name]
+        self.f[off:off + n] = np.asarray(value, dtype=np.float32).reshape(-1) if n == 3 else np.float32(value)
+        return self
+
+    def get(self, name):
+        off, n = self.NAMES[name]
+        return self.f[off:off + n].copy() if n == 3 else float(self.f[off])
+
+    def ptr(self):
+        return _fptr(self.f)
+
+
+def blue_noise_table():
+    """The 64x64x2 table `initBlueNoise()` uploads (common/bluenoise.cuh:79-198), libstdc++ build."""
+    t = np.zeros(64 * 64 * 2, dtype=np.float32)
+    lib.hs_blue_noise_table(_fptr(t))
+    return t
+
+
+class Scene:
+    """The reference's `Scene` host API; see host/ptrt/scene.hpp for per-method citations."""
+
+    def __init__(self, width, height, tile_y0=0, tile_rows=0, device=0):
+        self.width, self.height = int(width), int(height)
+        self.tile_y0 = int(tile_y0)
+        self.tile_rows = int(tile_rows) if tile_rows > 0 else self.height
+        self.device = device
+        self._h = lib.hs_scene_create(self.width, self.height, tile_y0, tile_rows, device)
+        if not self._h:
+            raise PtrtError(lib.hs_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.hs_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise PtrtError(lib.hs_last_error().decode())
+        return rc
+
+    @property
+    def ctx(self):
+        return lib.hs_backend(self._h)
+
+    def _cchk(self, rc):
+        if rc != PTRT_OK:
+            raise PtrtError(lib.ptrt_last_error(self.ctx).decode())
+
+    # geometry
+    def addCube(self, mat): return self._chk(lib.hs_add_cube(self._h, mat.ptr()))
+    def addSphere(self, segments, mat): return self._chk(lib.hs_add_sphere(self._h, segments, mat.ptr()))
+    def addPlaneXZ(self, y, half, mat): return self._chk(lib.hs_add_plane_xz(self._h, y, half, mat.ptr()))
+
+    def addTriangles(self, tris, mat):
+        a = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+        return self._chk(lib.hs_add_triangles(self._h, _fptr(a), a.shape[0], mat.ptr()))
+
+    def addMesh(self, path, mat): return self._chk(lib.hs_add_mesh_obj(self._h, path.encode(), mat.ptr()))
+
+    def addCheckerboardPlaneXZ(self, y, tiles, tile_size, white, black):
+        self._chk(lib.hs_add_checkerboard(self._h, y, tiles, tile_size, white.ptr(), black.ptr()))
+
+    def _op(self, mesh, op, v): self._chk(lib.hs_mesh_op(self._h, mesh, op, float(v[0]), float(v[1]), float(v[2])))
+    def scale(self, mesh, s): self._op(mesh, 0, (s, s, s) if np.isscalar(s) else s)
+    def translate(self, mesh, d): self._op(mesh, 1, d)
+    def moveTo(self, mesh, p): self._op(mesh, 2, p)
+    def rotateSelfEulerXYZ(self, mesh, r): self._op(mesh, 3, r)
+    def setPosition(self, mesh, p): self._op(mesh, 4, p)
+    def setRotation(self, mesh, r): self._op(mesh, 5, r)
+    def setInstanceScale(self, mesh, s): self._op(mesh, 6, s)
+
+    def setVertices(self, mesh, xyz):
+        a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self._chk(lib.hs_mesh_set_vertices(self._h, mesh, _fptr(a), a.shape[0]))
+
+    def meshCounts(self, mesh):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._chk(lib.hs_mesh_counts(self._h, mesh, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # lights / camera / sky
+    def addPointLight(self, pos, col, intensity=1.0, range=100.0, radius=0.0):
+        lib.hs_add_point_light(self._h, _f3(pos), _f3(col), intensity, range, radius)
+
+    def addDirectionalLight(self, direction, col, intensity=1.0):
+        lib.hs_add_directional_light(self._h, _f3(direction), _f3(col), intensity)
+
+    def addSpotLight(self, pos, direction, col, intensity=1.0, inner=0.5, outer=0.7, range=100.0, radius=0.0):
+        lib.hs_add_spot_light(self._h, _f3(pos), _f3(direction), _f3(col), intensity, inner, outer, range, radius)
+
+    def moveLightTo(self, i, pos): lib.hs_move_light_to(self._h, i, _f3(pos))
+
+    def setCamera(self, lookfrom, lookat, vup, vfov, aperture=0.0, focus_dist=1.0):
+        lib.hs_set_camera(self._h, _f3(lookfrom), _f3(lookat), _f3(vup), vfov, aperture, focus_dist)
+
+    def moveCamera(self, pos): lib.hs_move_camera(self._h, _f3(pos))
+    def lookCameraAt(self, at): lib.hs_look_camera_at(self._h, _f3(at))
+    def setSkyGradient(self, top, bottom): lib.hs_set_sky_gradient(self._h, _f3(top), _f3(bottom))
+    def disableSky(self): lib.hs_disable_sky(self._h)
+
+    # settings
+    def setBVHLeafTarget(self, target, tol=5): lib.hs_set_bvh_leaf_target(self._h, target, tol)
+    def setMaxBounceDepth(self, d): lib.hs_set_max_bounce_depth(self._h, d)
+    def setSamplesPerPixel(self, n): lib.hs_set_samples_per_pixel(self._h, n)
+    def setDenoiserEnabled(self, e): lib.hs_set_denoiser_enabled(self._h, int(e))
+    def setBloomEnabled(self, e): lib.hs_set_bloom_enabled(self._h, int(e))
+    def setPerformancePreset(self, name): lib.hs_set_performance_preset(self._h, name.encode())
+    def setMeshMaterial(self, mesh, mat): self._chk(lib.hs_set_mesh_material(self._h, mesh, mat.ptr()))
+
+    def settings(self):
+        spp, depth, dn, bl, sc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        lib.hs_get_settings(self._h, C.byref(spp), C.byref(depth), C.byref(dn), C.byref(bl), C.byref(sc))
+        return dict(spp=spp.value, depth=depth.value, denoiser=bool(dn.value), bloom=bool(bl.value), scale=sc.value)
+
+    # upload / render
+    def initBlueNoise(self): self._chk(lib.hs_init_blue_noise(self._h))
+    def uploadToGPU(self): self._chk(lib.hs_upload(self._h))
+    def commitObjectChanges(self): self._chk(lib.hs_commit_object_changes(self._h))
+    def getFrameCount(self): return lib.hs_get_frame_count(self._h)
+    def setFrameCount(self, f): lib.hs_set_frame_count(self._h, f)
+
+    def render_to_device(self, device_ptr):
+        """`Scene::render_to_device(unsigned char*)`: asynchronous, RGB8 bottom-up into device memory."""
+        self._chk(lib.hs_render_to_device(self._h, C.c_void_p(device_ptr)))
+
+    def render_to_host(self):
+        out = np.empty((self.tile_rows, self.width, 3), dtype=np.uint8)
+        self._chk(lib.hs_render_to_host(self._h, out.ctypes.data_as(_vp)))
+        return out
+
+    def sync(self): self._cchk(lib.ptrt_sync(self.ctx))
+
+    def read(self, kind):
+        n = self.tile_rows * self.width
+        shape, dt = {BUF_ACCUM: ((n, 3), np.float32), BUF_NORMAL: ((n, 3), np.float32), BUF_DEPTH: ((n,), np.float32),
+                     BUF_OBJECT_ID: ((n,), np.int32), BUF_RGB8: ((self.tile_rows, self.width, 3), np.uint8),
+                     BUF_RNG: ((n, 6), np.uint32)}[kind]
+        out = np.empty(shape, dtype=dt)
+        self._cchk(lib.ptrt_read_buffer(self.ctx, kind, out.ctypes.data_as(_vp), out.nbytes))
+        return out
+
+    def write_rng(self, states):
+        a = np.ascontiguousarray(states, dtype=np.uint32)
+        self._cchk(lib.ptrt_write_rng(self.ctx, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.nbytes))
+
+    def reset_rng(self, seed=DEFAULT_SEED): self._cchk(lib.ptrt_reset_rng(self.ctx, seed))
+    def set_option(self, name, value): self._cchk(lib.ptrt_set_option(self.ctx, name.encode(), int(value)))
+
+    def stats(self):
+        s = Stats()
+        self._cchk(lib.ptrt_get_stats(self.ctx, C.byref(s)))
+        return dict(extension_rays=s.extension_rays, shadow_rays=s.shadow_rays, paths=s.paths)
+
+    def last_kernel_ms(self):
+        a = C.c_float()
+        self._cchk(lib.ptrt_last_kernel_ms(self.ctx, C.byref(a), None))
+        return a.value
+
+    def trace_rays(self, origins, directions):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(o.shape[0], dtype=HIT_DTYPE)
+        self._cchk(lib.ptrt_trace_rays(self.ctx, _fptr(o), _fptr(d), o.shape[0], out.ctypes.data_as(_vp)))
+        return out
+
+    def traceSingleRay(self, origin, direction):
+        h = Hit()
+        self._chk(lib.hs_trace_single_ray(self._h, _f3(origin), _f3(direction), C.byref(h)))
+        return h
+
+    def saveAsPPM(self, path, pixels):
+        a = np.ascontiguousarray(pixels, dtype=np.uint8)
+        self._chk(lib.hs_save_ppm(self._h, path.encode(), a.ctypes.data_as(_vp)))
+
+    def flatten(self):
+        """Pointer to the flattened `ptrt_scene_desc` (host arrays owned by the C++ Scene)."""
+        p = lib.hs_flatten(self._h)
+        if not p:
+            raise PtrtError(lib.hs_last_error().decode())
+        return p
+
+
+from . import scenes  # noqa: E402,F401

@@ -1,0 +1,137 @@
+"""Scene recipes for the measured configurations, written against the
+`Scene` host API exactly as an application of the reference would write them.
+
+  cornell(scene)   "CORNELL-REF": DemoScenes::createCornellBox layout
+                   (src/raytracer/RTapp_utils.cuh:251-312) expressed through the PT Scene API:
+                   8 cube meshes, 96 triangles, 1 point light, sky disabled.
+  showcase(scene)  stand-in for reference scene 8 (src/pathtracer/app_utils.cuh:585-679), whose
+                   OBJ assets are not in the repository: 10 x addSphere(71) (100,820 triangles)
+                   at the scene-8 positions with the scene-8 materials, lights and camera,
+                   plus an addPlaneXZ floor.
+  fluid(scene, t)  dynamic height-field "water" over a static sphere "ship" (config 5).
+"""
+import math
+
+import numpy as np
+
+from . import Material
+
+WHITE = dict(albedo=(0.73, 0.73, 0.73), roughness=0.6)
+RED = dict(albedo=(0.65, 0.05, 0.05), roughness=0.6)
+GREEN = dict(albedo=(0.12, 0.45, 0.15), roughness=0.6)
+
+
+def cornell(scene, quads=False):
+    """Canonical Cornell box; ``quads=True`` swaps the five wall slabs for 2-triangle quads."""
+    white, red, green = Material(**WHITE), Material(**RED), Material(**GREEN)
+    light = Material(albedo=(0.0, 0.0, 0.0), roughness=0.0, emission=(15.0, 15.0, 15.0))
+    box = Material(albedo=(0.9, 0.9, 0.9), roughness=0.2)
+
+    def slab(mat, scale, pos, rot=None):
+        m = scene.addCube(mat)
+        scene.scale(m, scale)
+        scene.moveTo(m, pos)
+        if rot is not None:
+            scene.rotateSelfEulerXYZ(m, rot)
+        return m
+
+    if not quads:
+        slab(white, (10.0, 10.0, 0.1), (0, 0, -10))   # back
+        slab(red, (0.1, 10.0, 10.0), (-5, 0, -5))     # left
+        slab(green, (0.1, 10.0, 10.0), (5, 0, -5))    # right
+        slab(white, (10.0, 0.1, 10.0), (0, -5, -5))   # floor
+        slab(white, (10.0, 0.1, 10.0), (0, 5, -5))    # ceiling
+    else:
+        def quad(mat, a, b, c, d):
+            scene.addTriangles([a + b + c, a + c + d], mat)
+        quad(white, (-5, -5, -10), (5, -5, -10), (5, 5, -10), (-5, 5, -10))
+        quad(red, (-5, -5, 0), (-5, -5, -10), (-5, 5, -10), (-5, 5, 0))
+        quad(green, (5, -5, -10), (5, -5, 0), (5, 5, 0), (5, 5, -10))
+        quad(white, (-5, -5, 0), (5, -5, 0), (5, -5, -10), (-5, -5, -10))
+        quad(white, (-5, 5, -10), (5, 5, -10), (5, 5, 0), (-5, 5, 0))
+    slab(light, (2.0, 0.1, 2.0), (0, 4.9, -5))
+    slab(box, (1.5, 3.0, 1.5), (-1.5, -3.5, -6), (0, 0.3, 0))
+    slab(box, (1.5, 1.5, 1.5), (1.5, -4.25, -4), (0, -0.4, 0))
+    scene.addPointLight((0, 4.5, -5), (1.0, 0.9, 0.8), 3.0, 20.0)
+    scene.setCamera((0, 0, 5), (0, 0, -5), (0, 1, 0), 40.0)
+    scene.disableSky()
+    return scene
+
+
+def _showcase_materials():
+    m = []
+    m.append(Material((0.95, 0.64, 0.54), 0.2, 1.0))                                   # Copper
+    m.append(Material((0.95, 0.95, 0.95), 0.1, 0.5))                                   # MarbleCarrara
+    m.append(Material((0.1, 0.6, 0.3), 0.4, subsurfaceRadius=1.0, subsurfaceColor=(0.1, 0.8, 0.4)))  # Jade
+    m.append(Material((1.0, 1.0, 1.0), 0.0, transmission=0.95, ior=1.01, iridescence=1.0,
+                      iridescenceThickness=400.0))                                     # SoapBubble
+    m.append(Material((0.542, 0.497, 0.449), 0.15, 1.0))                               # Titanium
+    # CarPaintMidnight: metallic is assigned AFTER construction, so specular stays 0.04 (app_utils.cuh:133-139)
+    m.append(Material((0.02, 0.02, 0.15), 0.5, clearcoat=1.0, clearcoatRoughness=0.01).set("metallic", 0.4))
+    m.append(Material((1.00, 0.78, 0.34), 0.1, 1.0))                                   # Gold
+    m.append(Material((0.9, 0.8, 0.5), 0.3, transmission=0.2))                         # Wax
+    m.append(Material((0.4, 0.01, 0.05), 0.8, sheen=1.0, sheenTint=(1.0, 0.5, 0.5)))   # VelvetRed
+    f0 = np.float32((np.float32(1.5) - np.float32(1.0)) / (np.float32(1.5) + np.float32(1.0)))
+    f0 = float(f0 * f0)                                                                # iorToF0(1.5)
+    m.append(Material((1.0, 1.0, 1.0), 0.0, transmission=1.0, ior=1.5, specular=(f0, f0, f0)))  # Glass
+    return m
+
+
+def showcase(scene, segments=71):
+    """~100k-triangle BVH scene (config 3/4). `segments` scales the triangle count: 2*segments^2 per sphere."""
+    floor_y = 2.0 - 10.0 / 2.0
+    xs = (-8, -4, 0, 4, 8)
+    mats = _showcase_materials()
+    heights = [3.0, 2.0, 3.0, 3.0, 3.0, 3.0, 2.0, 3.0, 3.0, 3.0]
+    rot = (0, 0.3, 0)
+    for i in range(10):
+        z = -12 if i < 5 else -8
+        mesh = scene.addSphere(segments, mats[i])
+        scene.scale(mesh, 3.0)
+        scene.moveTo(mesh, (xs[i % 5], floor_y + heights[i], z))
+        scene.rotateSelfEulerXYZ(mesh, rot)
+    scene.addPlaneXZ(floor_y, 50.0, Material((0.4, 0.4, 0.4), 0.9, specular=(0.0, 0.0, 0.0)))
+    scene.setSkyGradient((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    one = (1.0, 1.0, 1.0)
+    scene.addSpotLight((0, 6.5, -10), (0, -1, 0), one, 15.0, 0.1, 0.8, 2.0, 0.1)
+    scene.addSpotLight((-6, 6.5, -10), (0, -1, 0), one, 12.0, 0.1, 0.8, 2.0, 0.1)
+    scene.addSpotLight((6, 6.5, -10), (0, -1, 0), one, 12.0, 0.1, 0.8, 2.0, 0.1)
+    scene.addPointLight((0, 2, 4), (0.8, 0.8, 0.8), 5.0, 20.0, 0.1)
+    scene.addPointLight((-8, 1, 4), (0.5, 0.5, 0.5), 3.0, 20.0, 0.1)
+    scene.addPointLight((8, 1, 4), (0.5, 0.5, 0.5), 3.0, 20.0, 0.1)
+    cam_pos, cam_at = (0.0, 2.0, 5.0), (0.0, 0.0, -10.0)
+    focus = math.sqrt(sum((a - b) ** 2 for a, b in zip(cam_at, cam_pos)))
+    scene.setCamera(cam_pos, cam_at, (0, 1, 0), 50.0, 0.0, focus)
+    return scene
+
+
+_WAVES = ((0.35, (0.45, 0.20), 1.3), (0.20, (-0.30, 0.55), 2.1), (0.12, (0.80, -0.65), 3.4))
+
+
+def water_vertices(cells, t, half=20.0):
+    """Unshared-vertex height field (what addTriangles produces): cells*cells*2 triangles * 3 vertices."""
+    g = np.linspace(-half, half, cells + 1, dtype=np.float32)
+    x, z = np.meshgrid(g, g, indexing="xy")
+    y = np.zeros_like(x)
+    for a, (kx, kz), w in _WAVES:
+        y += np.float32(a) * np.sin(np.float32(kx) * x + np.float32(kz) * z - np.float32(w * t)).astype(np.float32)
+    p = np.stack([x, y, z], axis=-1)
+    a, b = p[:-1, :-1], p[:-1, 1:]
+    c, d = p[1:, 1:], p[1:, :-1]
+    tris = np.stack([np.stack([a, c, b], axis=2), np.stack([a, d, c], axis=2)], axis=2)  # CCW from +Y
+    return np.ascontiguousarray(tris.reshape(-1, 3), dtype=np.float32)
+
+
+def fluid(scene, cells=256, t=0.0, ship_segments=100):
+    """Config 5: water surface (2*cells^2 triangles, re-posed per frame) over a static 'ship'."""
+    water = Material((1.0, 1.0, 1.0), 0.0, transmission=1.0, ior=1.33,
+                     specular=(0.04, 0.04, 0.04))
+    v = water_vertices(cells, t)
+    w = scene.addTriangles(v.reshape(-1, 9), water)
+    ship = scene.addSphere(ship_segments, Material((0.6, 0.35, 0.2), 0.5))
+    scene.scale(ship, (6.0, 2.0, 3.0))
+    scene.moveTo(ship, (0.0, 0.4, -2.0))
+    scene.setSkyGradient((0.35, 0.55, 0.95), (0.9, 0.95, 1.0))
+    scene.addDirectionalLight((-0.4, -1.0, -0.3), (1.0, 0.96, 0.9), 3.0)
+    scene.setCamera((0.0, 6.0, 18.0), (0.0, 0.0, 0.0), (0, 1, 0), 45.0)
+    return w, ship

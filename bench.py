@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X path-tracing render loop.
+
+One "step" = one frame of the hot path (acceleration-structure check, path trace + fused
+tonemap, and for N > 1 the RCCL gather of the tile images to rank 0).  At N = 1 the workload is
+BASELINE.json configs[1]: Cornell box, 1920x1080, 4 spp, 4 bounces.  For N > 1 the SAME frame is
+split into N horizontal bands (one process per GPU, scene replicated, per-pixel random streams
+keyed by the global pixel index, so the image is bit-identical to the 1-GPU frame) -> strong
+scaling.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 30 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ptrt-game-engine_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_PIXEL = 143.0   # RNG 48R+48W, accum 12W, normal 12W, depth 4W, id 4W, tonemap 12R+3W
+
+
+def build_scene(P, name, W, H, y0, rows, device):
+    s = P.Scene(W, H, tile_y0=y0, tile_rows=rows, device=device)
+    if name == "cornell":
+        P.scenes.cornell(s)
+    elif name == "showcase":
+        P.scenes.showcase(s)
+    else:
+        raise SystemExit(f"unknown scene {name}")
+    s.setDenoiserEnabled(False)
+    s.setBloomEnabled(False)
+    return s
+
+
+def cpu_baseline(P, scene_name, W, H, spp, depth, frame, threads):
+    """The oracle ("port" of the reference path; the reference has no CPU renderer) timed on this
+    box's host cores over a bounded sample: the full frame once for Cornell."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    s = build_scene(P, scene_name, W, H, 0, 0, P.HOST_ONLY)
+    s.setSamplesPerPixel(spp)
+    s.setMaxBounceDepth(depth)
+    desc = s.flatten()
+    rows = H if scene_name == "cornell" else max(8, H // 8)
+    y0 = (H - rows) // 2
+    rng = O.xorwow_init(P.DEFAULT_SEED, y0 * W, rows * W)
+    bn = P.blue_noise_table()
+    t0 = time.perf_counter()
+    r = O.render(desc, W, H, spp, depth, frame, bn, rng, tile_y0=y0, tile_rows=rows, threads=threads)
+    dt = time.perf_counter() - t0
+    rays = r["stats"]["extension_rays"] + r["stats"]["shadow_rays"]
+    s.close()
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"rows {y0}..{y0 + rows} of one {W}x{H} frame, {spp} spp, {depth} bounces, "
+                      f"{rays} rays in {dt:.2f} s", "fps_equivalent": round(rows / H / dt, 4) if rows else None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ptrt_amd as P
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the render loop has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    # horizontal bands; the last rank takes the remainder rows
+    base = H // world
+    y0 = rank * base
+    rows = base if rank < world - 1 else H - y0
+    scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, local_rank)
+    scene.setSamplesPerPixel(args.spp)
+    scene.setMaxBounceDepth(args.depth)
+    scene.initBlueNoise()
+    scene.uploadToGPU()
+    scene.set_option("count_rays", 1)
+    # render on torch's current stream so the RCCL gather is ordered after the frame without host syncs
+    stream = torch.cuda.current_stream()
+    scene.set_stream(stream.cuda_stream)
+
+    tile = torch.empty((rows, W, 3), dtype=torch.uint8, device="cuda")
+    frame = None
+    gather_list = None
+    if world > 1 and rank == 0:
+        # RGB8 is bottom-up: band r (rows y0..y0+rows from the top) is byte rows H-(y0+rows)..H-y0
+        frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        gather_list = []
+        for r in range(world):
+            ry0 = r * base
+            rr = base if r < world - 1 else H - ry0
+            gather_list.append(frame[H - (ry0 + rr):H - ry0])
+    uneven = world > 1 and (H % world != 0)
+
+    def step():
+        scene.render_to_device(tile.data_ptr())
+        if world > 1:
+            if uneven:  # dist.gather needs equal shapes: fall back to point-to-point
+                if rank == 0:
+                    gather_list[0].copy_(tile)
+                    reqs = [dist.irecv(gather_list[r], src=r) for r in range(1, world)]
+                    for q in reqs:
+                        q.wait()
+                else:
+                    dist.send(tile, dst=0)
+            else:
+                dist.gather(tile, gather_list if rank == 0 else None, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    scene.stats()  # reset counters
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    st = scene.stats()
+    rays = float(st["extension_rays"] + st["shadow_rays"])
+    kms = scene.kernel_ms_history(args.steps)
+    kernel_ms = float(kms.mean()) if len(kms) else float("nan")
+    if world > 1:
+        t = torch.tensor([dt, rays, kernel_ms], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        rays = float(tsum[1])
+        kernel_ms = float(tmax[2])
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    mrays = rays / dt / 1e6
+    fps = args.steps / dt
+    tile_pixels = W * rows  # rank 0's launch
+    algo_bytes = ALGO_BYTES_PER_PIXEL * tile_pixels
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms and kernel_ms > 0 else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{args.scene}_{W}x{H}_{args.spp}spp_{args.depth}b"
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "fps": round(fps, 2),
+        "rays_per_frame": round(rays / args.steps),
+        "config": {"workload": f"{args.scene} {W}x{H} {args.spp}spp {args.depth}-bounce", "scene": args.scene,
+                   "width": W, "height": H, "spp": args.spp, "max_depth": args.depth,
+                   "parallelism": f"tile{world}" if world > 1 else "single",
+                   "kernel": "path_trace_kernel (megakernel, fused tonemap)"},
+        "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6),
+                     "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "note": "path is VALU/latency bound, not HBM bound (SURVEY 8(d)); see DESIGN.md"},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(P, args.scene, W, H, args.spp, args.depth, 0,
+                                           min(16, len(os.sched_getaffinity(0))))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -251,6 +251,17 @@ int ptrt_get_stats(ptrt_ctx *ctx, ptrt_stats *out);
 /* tuning / diagnostics knobs, by name; unknown names return PTRT_E_INVALID */
 int ptrt_set_option(ptrt_ctx *ctx, const char *name, long long value);
 
+/* Render on a caller-owned HIP stream (a `hipStream_t` passed as void*; NULL returns to the
+ * context's own stream).  Lets a host that already orders work on a stream (a GL-interop map,
+ * an RCCL gather) enqueue frames without host synchronisation, like the reference's use of
+ * the default stream (SURVEY 8(b) "Threading / streams"). */
+int ptrt_set_stream(ptrt_ctx *ctx, void *hip_stream);
+
+/* Durations (ms) of the most recent path-trace kernel launches, oldest first, measured with
+ * HIP events on the stream the kernel ran on; at most 256 are kept.  Synchronises.  Returns
+ * the number written (<= max_n) or a negative error. */
+int ptrt_kernel_ms_history(ptrt_ctx *ctx, float *out_ms, int max_n);
+
 /* duration in milliseconds of the last ptrt_render's path-trace kernel and
  * tonemap kernel, measured with HIP events on the context's stream
  * (synchronises).  Either pointer may be NULL. */

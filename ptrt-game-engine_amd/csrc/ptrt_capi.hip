@@ -22,6 +22,7 @@
 
 namespace {
 
+constexpr int EV_RING = 256;
 thread_local std::string g_last_error = "";
 std::mutex g_live_mutex;
 std::set<ptrt_ctx *> g_live;
@@ -30,8 +31,9 @@ std::set<ptrt_ctx *> g_live;
 
 struct ptrt_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    std::vector<hipEvent_t> ev_ring; // 2 * EV_RING events: start/stop per launch
+    unsigned long long launches = 0;
     int W = 0, H = 0, y0 = 0, rows = 0;
     size_t npix = 0;
     std::string err;
@@ -372,8 +374,10 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
     int rc = set_device(c);
     if (rc)
         return rc;
-    HIP_TRY(c, hipStreamCreate(&c->stream));
-    for (auto &ev : c->ev)
+    HIP_TRY(c, hipStreamCreate(&c->own_stream));
+    c->stream = c->own_stream;
+    c->ev_ring.assign(2 * EV_RING, nullptr);
+    for (auto &ev : c->ev_ring)
         HIP_TRY(c, hipEventCreate(&ev));
     HIP_TRY(c, hipMalloc((void **)&c->d_rng, c->npix * 6 * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_accum, c->npix * 3 * sizeof(float)));
@@ -427,11 +431,11 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_counters);
     dfree(c->d_blue);
     dfree(c->d_jump);
-    for (auto &ev : c->ev)
+    for (auto &ev : c->ev_ring)
         if (ev)
             (void)hipEventDestroy(ev);
-    if (c->stream)
-        (void)hipStreamDestroy(c->stream);
+    if (c->own_stream)
+        (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -730,7 +734,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const int geom = pick_geom(c);
     const bool full = c->mats_full || c->force_full;
     const size_t lds = (geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2);
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    const int slot = (int)(c->launches % EV_RING);
+    HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
     if (geom == 0)
         launch_trace<0>(c, K, full, grid, lds);
     else if (geom == 1)
@@ -738,7 +743,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     else
         launch_trace<2>(c, K, full, grid, lds);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
+    c->launches++;
     c->timed = true;
     if (out_rgb8 && !out_is_device) {
         HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
@@ -761,14 +767,43 @@ int ptrt_last_kernel_ms(ptrt_ctx *c, float *trace_ms, float *tonemap_ms) {
         return fail(c, PTRT_E_NOT_READY, "ptrt_last_kernel_ms: nothing rendered yet");
     if (int rc = set_device(c))
         return rc;
-    HIP_TRY(c, hipEventSynchronize(c->ev[1]));
+    const int slot = (int)((c->launches - 1) % EV_RING);
+    HIP_TRY(c, hipEventSynchronize(c->ev_ring[2 * slot + 1]));
     float ms = 0.0f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_ring[2 * slot], c->ev_ring[2 * slot + 1]));
     if (trace_ms)
         *trace_ms = ms;
     if (tonemap_ms)
         *tonemap_ms = 0.0f; // the tonemap is fused into the path-trace kernel
     return PTRT_OK;
+}
+
+int ptrt_set_stream(ptrt_ctx *c, void *hip_stream) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_set_stream: bad context");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // finish what was queued on the old stream
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->launches = 0;
+    c->timed = false;
+    return PTRT_OK;
+}
+
+int ptrt_kernel_ms_history(ptrt_ctx *c, float *out_ms, int max_n) {
+    if (!ctx_live(c) || !out_ms || max_n < 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_kernel_ms_history: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long n = c->launches < (unsigned long long)EV_RING ? c->launches : EV_RING;
+    if (n > (unsigned long long)max_n)
+        n = max_n;
+    for (unsigned long long i = 0; i < n; ++i) {
+        const int slot = (int)((c->launches - n + i) % EV_RING);
+        HIP_TRY(c, hipEventElapsedTime(&out_ms[i], c->ev_ring[2 * slot], c->ev_ring[2 * slot + 1]));
+    }
+    return (int)n;
 }
 
 void *ptrt_device_buffer(ptrt_ctx *c, int kind) {

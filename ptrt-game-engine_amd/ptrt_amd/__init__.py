@@ -134,6 +134,8 @@ _sig("ptrt_trace_rays", C.c_int, _vp, _fp, _fp, C.c_int, _vp)
 _sig("ptrt_get_stats", C.c_int, _vp, C.POINTER(Stats))
 _sig("ptrt_set_option", C.c_int, _vp, C.c_char_p, C.c_longlong)
 _sig("ptrt_last_kernel_ms", C.c_int, _vp, _fp, _fp)
+_sig("ptrt_set_stream", C.c_int, _vp, _vp)
+_sig("ptrt_kernel_ms_history", C.c_int, _vp, _fp, C.c_int)
 _sig("ptrt_debug_detmath", C.c_int, _vp, C.c_int, _fp, _fp, C.c_int, _fp)
 
 # ---- Scene mirror (csrc/ptrt_host_capi.cpp) ---------------------------------------------
@@ -378,6 +380,16 @@ class Scene:
         a = C.c_float()
         self._cchk(lib.ptrt_last_kernel_ms(self.ctx, C.byref(a), None))
         return a.value
+
+    def set_stream(self, hip_stream):
+        self._cchk(lib.ptrt_set_stream(self.ctx, C.c_void_p(hip_stream)))
+
+    def kernel_ms_history(self, max_n=256):
+        out = np.zeros(max_n, dtype=np.float32)
+        n = lib.ptrt_kernel_ms_history(self.ctx, _fptr(out), max_n)
+        if n < 0:
+            raise PtrtError(lib.ptrt_last_error(self.ctx).decode())
+        return out[:n]
 
     def trace_rays(self, origins, directions):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

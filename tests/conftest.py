@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "ptrt-game-engine_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def P():
+    import ptrt_amd
+    return ptrt_amd
+
+
+@pytest.fixture(scope="session")
+def O():
+    import oracle
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def blue_noise(P):
+    return P.blue_noise_table()

@@ -90,11 +90,9 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from ptrt_amd import tilefarm
     W, H = args.width, args.height
-    # horizontal bands; the last rank takes the remainder rows
-    base = H // world
-    y0 = rank * base
-    rows = base if rank < world - 1 else H - y0
+    y0, rows = tilefarm.bands(H, world)[rank]  # horizontal bands; the last rank takes the remainder rows
     scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, local_rank)
     scene.setSamplesPerPixel(args.spp)
     scene.setMaxBounceDepth(args.depth)
@@ -106,31 +104,14 @@ def main():
     scene.set_stream(stream.cuda_stream)
 
     tile = torch.empty((rows, W, 3), dtype=torch.uint8, device="cuda")
-    frame = None
-    gather_list = None
+    views = None
     if world > 1 and rank == 0:
-        # RGB8 is bottom-up: band r (rows y0..y0+rows from the top) is byte rows H-(y0+rows)..H-y0
         frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
-        gather_list = []
-        for r in range(world):
-            ry0 = r * base
-            rr = base if r < world - 1 else H - ry0
-            gather_list.append(frame[H - (ry0 + rr):H - ry0])
-    uneven = world > 1 and (H % world != 0)
+        views = tilefarm.frame_views(frame, H, world)
 
     def step():
         scene.render_to_device(tile.data_ptr())
-        if world > 1:
-            if uneven:  # dist.gather needs equal shapes: fall back to point-to-point
-                if rank == 0:
-                    gather_list[0].copy_(tile)
-                    reqs = [dist.irecv(gather_list[r], src=r) for r in range(1, world)]
-                    for q in reqs:
-                        q.wait()
-                else:
-                    dist.send(tile, dst=0)
-            else:
-                dist.gather(tile, gather_list if rank == 0 else None, dst=0)
+        tilefarm.gather_bands(dist, tile, views, rank, world, H)
 
     def fence():
         if world > 1:

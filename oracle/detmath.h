@@ -16,7 +16,7 @@
  * glibc's and from ROCm's by ulps, so no choice of libm reproduces the CUDA
  * binary; choosing one arithmetic for oracle AND kernel is what makes the
  * radiance comparison exact instead of statistical.  Accuracy: <= 2 ulp on the
- * ranges the path uses (measured in tests/test_detmath.py).
+ * ranges the path uses, pow <= 5 ulp (measured in tests/test_detmath.py).
  */
 #ifndef PTRT_ORACLE_DETMATH_H
 #define PTRT_ORACLE_DETMATH_H

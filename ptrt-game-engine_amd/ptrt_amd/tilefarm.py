@@ -1,0 +1,41 @@
+"""Tile farm: split one frame into horizontal bands, one per rank, and gather the RGB8 band images
+onto the presenting rank.  Pure plumbing over torch.distributed (backend "nccl" =
+RCCL over xGMI on the GPU box, "gloo" in CPU tests); no pixel is computed here.
+
+Bands are contiguous rows from the TOP of the view; the RGB8 image is bottom-up
+(scene.cuh:2013-2015), so band r -- rows [y0, y0+rows) -- occupies byte rows
+[H-(y0+rows), H-y0) of the assembled frame, and each band image is itself bottom-up, which makes
+the assembled frame a plain concatenation of the band images in reverse rank order.
+"""
+
+
+def bands(height, world):
+    """[(y0, rows)] per rank; the last rank takes the remainder."""
+    base = height // world
+    out = []
+    for r in range(world):
+        y0 = r * base
+        out.append((y0, base if r < world - 1 else height - y0))
+    return out
+
+
+def frame_views(frame, height, world):
+    """Views into a (H, W, 3) uint8 frame, one per rank, where that rank's band image lands."""
+    return [frame[height - (y0 + rows):height - y0] for (y0, rows) in bands(height, world)]
+
+
+def gather_bands(dist, tile, views, rank, world, height):
+    """Collective: every rank contributes `tile` (rows, W, 3); rank 0 receives all into `views`.
+    Equal bands use one gather; a remainder band falls back to point-to-point."""
+    if world == 1:
+        return
+    if height % world == 0:
+        dist.gather(tile, views if rank == 0 else None, dst=0)
+        return
+    if rank == 0:
+        views[0].copy_(tile)
+        reqs = [dist.irecv(views[r], src=r) for r in range(1, world)]
+        for q in reqs:
+            q.wait()
+    else:
+        dist.send(tile, dst=0)

@@ -4,7 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "ptrt-game-engine_amd"), os.path.join(ROOT, "oracle"), ROOT):
+for p in (os.path.join(ROOT, "ptrt-game-engine_amd"), os.path.join(ROOT, "oracle"), ROOT,
+          os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -1,0 +1,115 @@
+"""GPU checks that are not whole-frame parity: deterministic math bit-equality, committed goldens,
+error behaviour of the C ABI on a live device, size-independent properties at the benchmark size."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_detmath_bits_match_oracle(P, O):
+    s = P.Scene(16, 16)
+    rs = np.random.RandomState(5)
+    cases = [(0, rs.uniform(-50, 50, 1 << 16)), (1, rs.uniform(-50, 50, 1 << 16)), (0, np.linspace(0, 6.2831855, 1 << 16)),
+             (2, rs.uniform(-110, 90, 1 << 16)), (3, np.exp(rs.uniform(-100, 88, 1 << 16))),
+             (3, np.array([0.0, -1.0, np.inf, 1e-40, 1.0, np.nan])), (2, np.array([np.nan, -200.0, 100.0, 0.0]))]
+    for op, x in cases:
+        x = x.astype(np.float32)
+        out = np.zeros_like(x)
+        rc = P.lib.ptrt_debug_detmath(s.ctx, op, x.ctypes.data_as(C.POINTER(C.c_float)), None, x.size,
+                                      out.ctypes.data_as(C.POINTER(C.c_float)))
+        assert rc == 0
+        assert np.array_equal(out.view(np.uint32), O.detmath(op, x).view(np.uint32)), op
+    z = rs.uniform(0.003, 1.0, 1 << 16).astype(np.float32)
+    y = np.full_like(z, np.float32(1.0 / 2.4))
+    out = np.zeros_like(z)
+    P.lib.ptrt_debug_detmath(s.ctx, 4, z.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                             z.size, out.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(out.view(np.uint32), O.detmath(4, z, y).view(np.uint32))
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_64x64_1spp_d4_f0", "cornell_64x64_4spp_d2_f3", "showcase12_64x48_2spp_d5_f0"])
+def test_gpu_reproduces_committed_goldens(P, name):
+    import make_oracle_golden as M
+    scene, w, h, spp, depth, frame = M.CASES[name]
+    g = np.load(os.path.join(GOLD, f"oracle_{name}.npz"))
+    s = P.Scene(w, h)
+    P.scenes.cornell(s) if scene == "cornell" else P.scenes.showcase(s, segments=12)
+    s.setSamplesPerPixel(spp)
+    s.setMaxBounceDepth(depth)
+    s.initBlueNoise()
+    s.uploadToGPU()
+    s.setFrameCount(frame)
+    rgb = s.render_to_host()
+    assert np.array_equal(s.read(P.BUF_OBJECT_ID), g["object_id"])
+    assert np.array_equal(s.read(P.BUF_ACCUM).view(np.uint32), g["accum"].view(np.uint32))
+    assert np.array_equal(s.read(P.BUF_DEPTH).view(np.uint32), g["depth"].view(np.uint32))
+    assert np.array_equal(rgb, g["rgb8"])
+    s.close()
+
+
+def test_render_before_upload_and_bad_scenes(P):
+    s = P.Scene(32, 32)
+    assert P.lib.ptrt_render(s.ctx, 0, 1, 1, None, 0) == -4          # PTRT_E_NOT_READY
+    assert b"geometry" in P.lib.ptrt_last_error(s.ctx)
+    P.scenes.cornell(s)
+    s.uploadToGPU()
+    assert P.lib.ptrt_render(s.ctx, 0, 0, 4, None, 0) == -1          # spp < 1
+    # a face index out of range is rejected at upload, not discovered by a faulting kernel
+    d = s.flatten().contents
+    bad = (P.Tri * 12)(*[P.Tri(0, 1, 99) for _ in range(12)])
+    m0 = d.meshes[0]
+    keep = m0.faces
+    m0.faces = C.cast(bad, C.POINTER(P.Tri))
+    rc = P.lib.ptrt_upload_geometry(s.ctx, d.meshes, d.mesh_count, d.tlas_nodes, d.tlas_node_count,
+                                    d.tlas_mesh_indices, d.tlas_index_count)
+    m0.faces = keep
+    assert rc == -1 and b"vertex out of range" in P.lib.ptrt_last_error(s.ctx)
+    s.close()
+
+
+def test_full_size_properties(P):
+    """1920x1080, 4 spp, 4 bounces (BASELINE configs[1]): properties that need no oracle run."""
+    s = P.Scene(1920, 1080)
+    P.scenes.cornell(s)
+    s.setSamplesPerPixel(4)
+    s.setMaxBounceDepth(4)
+    s.initBlueNoise()
+    s.uploadToGPU()
+    s.set_option("count_rays", 1)
+    rng0 = s.read(P.BUF_RNG)
+    rgb = s.render_to_host()
+    st = s.stats()
+    acc, oid, dep, nrm, rng1 = (s.read(k) for k in (P.BUF_ACCUM, P.BUF_OBJECT_ID, P.BUF_DEPTH, P.BUF_NORMAL, P.BUF_RNG))
+    n = 1920 * 1080
+    assert st["paths"] == 4 * n and 4.5 < (st["extension_rays"] + st["shadow_rays"]) / st["paths"] < 5.3
+    assert np.isfinite(acc).all() and acc.min() >= 0 and (0.2126 * acc[:, 0] + 0.7152 * acc[:, 1] + 0.0722 * acc[:, 2]).max() <= 100.0001
+    assert (oid >= 0).all() and (oid < 8).all() and np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-5)
+    draws = ((rng1[:, 0].astype(np.int64) - rng0[:, 0]) % (1 << 32)) // 362437
+    assert draws.min() >= 4 * 3 and draws.max() <= 4 * 17           # Appendix C budget per sample
+    assert np.array_equal(rng1[:, 0] - rng0[:, 0], (draws * 362437).astype(np.uint32))
+    # left-right symmetry of the box geometry: object ids of walls mirror (1 <-> 2), others keep
+    ids = oid.reshape(1080, 1920)
+    mirror = ids[:, ::-1].copy()
+    sw = mirror.copy()
+    sw[mirror == 1], sw[mirror == 2] = 2, 1
+    walls = np.isin(ids, (0, 3, 4)) & np.isin(sw, (0, 3, 4, 1, 2))
+    assert (ids[walls] == sw[walls]).mean() > 0.99
+    # the same frame rendered as two bands is the same bytes
+    top = P.Scene(1920, 1080, tile_y0=0, tile_rows=536)
+    bot = P.Scene(1920, 1080, tile_y0=536, tile_rows=544)
+    parts = []
+    for t in (top, bot):
+        P.scenes.cornell(t)
+        t.setSamplesPerPixel(4)
+        t.setMaxBounceDepth(4)
+        t.initBlueNoise()
+        t.uploadToGPU()
+        parts.append(t.render_to_host())
+        t.close()
+    assert np.array_equal(np.concatenate([parts[1], parts[0]], axis=0), rgb)
+    s.close()

@@ -66,6 +66,10 @@ struct KParams {
     int tlas_root_ref; // >=0 inner node, <0 ~leaf
     int n_meshes, n_lights;
     int stack_entries; // LDS stack depth per lane (BLAS)
+    // pair-compacted tracing (pt_render.hip.h), valid when every BLAS is a single leaf
+    int pair_meshes;    // meshes in the (single) TLAS leaf
+    int pair_tri_slots; // triangle packets staged in LDS (all leaf slots, 0..n)
+    int pair_max_leaf;  // largest leaf
     // frame
     Camera cam;
     f3 sky_top, sky_bottom;
@@ -583,8 +587,10 @@ PT_DEV LightRec load_light(const float4 *__restrict__ L, int i) {
 }
 
 // ---------------------------------------------------------------------------------
-// the render loop
+// the render loop: see pt_render.hip.h (the first-round kernel below is kept for reference
+// only and is not compiled)
 // ---------------------------------------------------------------------------------
+#if 0
 template <int GEOM, bool FULL> __global__ __launch_bounds__(64) void path_trace_kernel(const KParams K) {
     extern __shared__ uint2 lds_stack[];
     const int lane = threadIdx.x;
@@ -826,6 +832,8 @@ template <int GEOM, bool FULL> __global__ __launch_bounds__(64) void path_trace_
         }
     }
 }
+
+#endif // first-round kernel
 
 // ---------------------------------------------------------------------------------
 // XORWOW initialisation: state(seed) advanced by `global pixel index` subsequences of

@@ -1,0 +1,505 @@
+// pt_render.hip.h -- path_trace_kernel<GEOM,FULL,PAIRS>: the render loop (round-1 second cut).
+//
+// Same outputs, bit for bit, as the first cut; what changed is how a wave spends its lanes:
+//
+//  * wave-uniform phases.  One iteration of the persistent loop is
+//        [A] regenerate finished paths            (divergent, cheap)
+//        [B] closest hit for every live lane      (wave-uniform call)
+//        [C] shade: emission, light sample        (divergent) -> shadow ray per lane
+//        [D] shadow any-hit for every lane that has one (wave-uniform call)
+//        [E] add the light sample, sample the BSDF, roulette, next ray (divergent)
+//    so both traversals run with all live lanes and may use wave collectives.
+//
+//  * PAIRS (scenes whose BLASes are all single leaves, e.g. the Cornell box): in-wave
+//    compaction of (ray, mesh) pairs.  A lane hits the root box of only ~1.7 of the 8
+//    Cornell meshes, but a lock-step mesh loop makes every lane sit through the union
+//    (~6-8 meshes) -> ~25 % useful lanes in the triangle tests.  Instead:
+//      1. every lane slab-tests all M root boxes (scalar-loaded boxes), and for each mesh
+//         the hitting lanes append {lane, mesh order} to an LDS pair list at
+//         base + mbcnt(ballot)                        (ballot / prefix-sum compaction)
+//      2. the P pairs are processed 64 at a time: lane j takes pair j, fetches that ray
+//         from LDS, walks the mesh's triangle packets (staged once per workgroup in LDS)
+//         and keeps the pair's closest hit
+//      3. per-ray merge with one LDS 64-bit atomic min on {t bits, mesh order, leaf index}:
+//         smallest t wins, ties go to the earlier mesh, then the earlier triangle -- exactly
+//         the reference's strict-`<` first-minimum (equivalence E3 in pt_kernels.hip.h).
+//    Shadow rays use the same pairs with an LDS flag per ray instead of the min.
+#pragma once
+#include "pt_kernels.hip.h"
+
+namespace pt {
+
+struct PairLds {
+    float4 *tris;             // pair_tri_slots * 3
+    int4 *meshtab;            // per mesh order: {first slot, count, flags, mesh id}
+    uint32_t *pairs;          // 64 * pair_meshes
+    float *ray;               // 6 planes of 64
+    unsigned long long *best; // 64
+    uint32_t *occ;            // 64
+};
+PT_DEV size_t pair_lds_bytes(int tri_slots, int meshes) {
+    return (size_t)tri_slots * 48 + (size_t)meshes * 16 + (size_t)meshes * 256 + 6 * 256 + 512 + 256;
+}
+PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes) {
+    PairLds l;
+    char *p = (char *)base;
+    l.tris = (float4 *)p;
+    p += (size_t)tri_slots * 48;
+    l.meshtab = (int4 *)p;
+    p += (size_t)meshes * 16;
+    l.best = (unsigned long long *)p;
+    p += 512;
+    l.pairs = (uint32_t *)p;
+    p += (size_t)meshes * 256;
+    l.ray = (float *)p;
+    p += 6 * 256;
+    l.occ = (uint32_t *)p;
+    return l;
+}
+
+PT_DEV int lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// step 1: root-box tests + ballot/prefix-sum compaction into the LDS pair list
+template <bool ANY>
+PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
+    const RayO w = make_ray(o, d);
+    float tE;
+    alive = alive && slab(mk3(K.tlas_root_min[0], K.tlas_root_min[1], K.tlas_root_min[2]),
+                          mk3(K.tlas_root_max[0], K.tlas_root_max[1], K.tlas_root_max[2]), w, ANY ? tMax : T_FAR, tE);
+    L.ray[0 * 64 + lane] = o.x;
+    L.ray[1 * 64 + lane] = o.y;
+    L.ray[2 * 64 + lane] = o.z;
+    L.ray[3 * 64 + lane] = d.x;
+    L.ray[4 * 64 + lane] = d.y;
+    L.ray[5 * 64 + lane] = d.z;
+    if (ANY)
+        L.occ[lane] = 0u;
+    else
+        L.best[lane] = ~0ull;
+    const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+    int base = 0;
+    for (int i = 0; i < lf.y; ++i) {
+        const int m = __builtin_amdgcn_readfirstlane(K.tlas_mesh_ids[lf.x + i]);
+        const MeshHead mh = load_mesh_head(K, m);
+        if (ANY && (mh.flags & 2))
+            continue;
+        bool hb;
+        if (mh.flags & 1) {
+            float ds;
+            const RayO lr = local_ray(K, m, w, ds);
+            hb = alive && slab(mh.bmin, mh.bmax, lr, ANY ? tMax * ds : T_FAR, tE);
+        } else {
+            hb = alive && slab(mh.bmin, mh.bmax, w, ANY ? tMax : T_FAR, tE);
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hb);
+        if (hb)
+            L.pairs[base + lane_prefix(bal)] = (uint32_t)lane | ((uint32_t)i << 8);
+        base += __builtin_popcountll(bal);
+    }
+    return base;
+}
+
+// ray of a pair in the mesh's space (tri_test needs origin and direction only)
+PT_DEV void pair_ray(const KParams &K, const PairLds &L, int r, const int4 mt, f3 &o, f3 &d, float &dirScale) {
+    o = mk3(L.ray[r], L.ray[64 + r], L.ray[128 + r]);
+    d = mk3(L.ray[192 + r], L.ray[256 + r], L.ray[320 + r]);
+    dirScale = 1.0f;
+    if (mt.z & 1) {
+        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
+        const f3 lo = xform_point(rec[2], rec[3], rec[4], o);
+        const f3 ld = xform_dir(rec[2], rec[3], rec[4], d);
+        dirScale = length(ld);
+        o = lo;
+        d = normalize(ld);
+    }
+}
+
+PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
+    const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
+    __syncthreads();
+    for (int c = 0; c < P; c += 64) {
+        const int p = c + lane;
+        const bool valid = p < P;
+        const uint32_t e = L.pairs[valid ? p : 0];
+        const int r = (int)(e & 63u), oi = (int)(e >> 8);
+        const int4 mt = L.meshtab[oi];
+        f3 po, pd;
+        float dirScale;
+        pair_ray(K, L, r, mt, po, pd, dirScale);
+        RayO pr;
+        pr.o = po;
+        pr.d = pd;
+        float tb = T_FAR;
+        int bi = -1;
+        for (int i = 0; i < K.pair_max_leaf; ++i) {
+            const int slot = mt.x + (i < mt.y ? i : 0);
+            const float4 p0 = L.tris[slot * 3 + 0], p1 = L.tris[slot * 3 + 1], p2 = L.tris[slot * 3 + 2];
+            float t, u, v;
+            const bool ok = tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tb, t, u, v);
+            if (ok && i < mt.y) {
+                tb = t;
+                bi = i;
+            }
+        }
+        if (valid && bi >= 0) {
+            const float tw = (mt.z & 1) ? tb / dirScale : tb;
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)oi << 16) | (uint32_t)bi;
+            __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    const unsigned long long key = L.best[lane];
+    __syncthreads(); // the lists are rebuilt by the next trace
+    Hit h;
+    h.u = h.v = 0.0f;
+    if (!alive || key == ~0ull) {
+        h.t = h.t_local = T_FAR;
+        h.mesh = -1;
+        h.slot = -1;
+        return h;
+    }
+    const int oi = (int)((key >> 16) & 0xffffu), bi = (int)(key & 0xffffu);
+    const int4 mt = L.meshtab[oi];
+    h.t = __uint_as_float((uint32_t)(key >> 32));
+    h.mesh = mt.w;
+    h.slot = mt.x + bi;
+    h.t_local = h.t;
+    if (mt.z & 1) { // local-space distance of the winner, needed for localPoint (intersection.cuh:382,466)
+        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
+        RayO pr;
+        pr.o = xform_point(rec[2], rec[3], rec[4], o);
+        pr.d = normalize(xform_dir(rec[2], rec[3], rec[4], d));
+        const float4 p0 = L.tris[h.slot * 3 + 0], p1 = L.tris[h.slot * 3 + 1], p2 = L.tris[h.slot * 3 + 2];
+        float t, u, v;
+        tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, T_FAR, t, u, v);
+        h.t_local = t;
+    }
+    return h;
+}
+
+PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
+    const int P = build_pairs<true>(K, L, lane, alive, o, d, tMax);
+    // per-lane tMax travels with the ray: reuse the `best` words as a float plane
+    float *tmaxv = (float *)L.best;
+    tmaxv[lane] = tMax;
+    __syncthreads();
+    for (int c = 0; c < P; c += 64) {
+        const int p = c + lane;
+        const bool valid = p < P;
+        const uint32_t e = L.pairs[valid ? p : 0];
+        const int r = (int)(e & 63u), oi = (int)(e >> 8);
+        const int4 mt = L.meshtab[oi];
+        f3 po, pd;
+        float dirScale;
+        pair_ray(K, L, r, mt, po, pd, dirScale);
+        RayO pr;
+        pr.o = po;
+        pr.d = pd;
+        float tm = tmaxv[r];
+        if (mt.z & 1)
+            tm = tm * dirScale;
+        bool found = false;
+        for (int i = 0; i < K.pair_max_leaf; ++i) {
+            const int slot = mt.x + (i < mt.y ? i : 0);
+            const float4 p0 = L.tris[slot * 3 + 0], p1 = L.tris[slot * 3 + 1], p2 = L.tris[slot * 3 + 2];
+            float t, u, v;
+            const bool ok = tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tm, t, u, v);
+            found |= ok && (i < mt.y);
+        }
+        if (valid && found)
+            L.occ[r] = 1u;
+    }
+    __syncthreads();
+    const bool occluded = alive && (L.occ[lane] != 0u);
+    __syncthreads();
+    return occluded;
+}
+
+// ---------------------------------------------------------------------------------
+template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void path_trace_kernel(const KParams K) {
+    extern __shared__ uint2 lds_raw[];
+    const int lane = threadIdx.x;
+    LdsStack stk{lds_raw + lane};
+    PairLds PL{};
+    if (PAIRS) {
+        PL = carve_pair_lds((void *)lds_raw, K.pair_tri_slots, K.pair_meshes);
+        for (int i = lane; i < K.pair_tri_slots * 3; i += 64)
+            PL.tris[i] = K.tris[i];
+        const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+        for (int i = lane; i < K.pair_meshes; i += 64) {
+            const int m = K.tlas_mesh_ids[lf.x + i];
+            const MeshHead mh = load_mesh_head(K, m);
+            const int2 leaf = K.leaves[~mh.root_ref];
+            PL.meshtab[i] = make_int4(leaf.x, leaf.y, mh.flags, m);
+        }
+        __syncthreads();
+    }
+    const int tile = blockIdx.x;
+    const int tx = tile % K.tiles_x, ty = tile / K.tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int yl = ty * 8 + (lane >> 3);
+    const bool inside = (x < K.width) && (yl < K.rows);
+    const int y = K.y0 + yl;
+    const size_t npix = (size_t)K.rows * K.width;
+    const size_t idx = (size_t)yl * K.width + x;
+
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    if (inside) {
+        rng.d = K.rng[idx];
+        rng.v0 = K.rng[npix + idx];
+        rng.v1 = K.rng[2 * npix + idx];
+        rng.v2 = K.rng[3 * npix + idx];
+        rng.v3 = K.rng[4 * npix + idx];
+        rng.v4 = K.rng[5 * npix + idx];
+    }
+
+    f3 avg_color = mk3(0.0f);
+    f3 first_normal = mk3(0.0f);
+    float first_depth = 1e30f;
+    int first_id = -1;
+    uint32_t n_ext = 0, n_shadow = 0;
+
+    int s = inside ? 0 : K.spp;
+    int bounce = 0;
+    bool fresh = true;
+    f3 ro = mk3(0.0f), rd = mk3(0.0f);
+    bool ray_spec = true, prev_was_specular = true;
+    f3 throughput = mk3(1.0f), acc = mk3(0.0f);
+
+    while (__builtin_amdgcn_ballot_w64(s < K.spp)) {
+        const bool live = s < K.spp;
+        // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
+        if (live && fresh) {
+            float tjx, tjy, bnx, bny;
+            taa_jitter(K.frame_count + s, tjx, tjy);
+            blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);
+            const float jitter_x = tjx + (bnx - 0.5f) * 0.25f;
+            const float jitter_y = tjy + (bny - 0.5f) * 0.25f;
+            const float u = ((float)x + 0.5f + jitter_x) / (float)K.width;
+            const float v = 1.0f - ((float)y + 0.5f + jitter_y) / (float)K.height;
+            if (K.cam.lens_radius <= 0) {
+                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin;
+                ro = K.cam.origin;
+                rd = normalize(dir);
+            } else {
+                f3 p;
+                do {
+                    const float a = rng_uniform(rng);
+                    const float b = rng_uniform(rng);
+                    p = 2.0f * mk3(a, b, 0.0f) - mk3(1.0f, 1.0f, 0.0f);
+                } while (dot(p, p) >= 1.0f);
+                const f3 rdisk = K.cam.lens_radius * p;
+                const f3 offset = K.cam.u * rdisk.x + K.cam.v * rdisk.y;
+                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin - offset;
+                ro = K.cam.origin + offset;
+                rd = normalize(dir);
+            }
+            ray_spec = true;
+            prev_was_specular = true;
+            throughput = mk3(1.0f);
+            acc = mk3(0.0f);
+            bounce = 0;
+            fresh = false;
+        }
+
+        // ---- [B] closest hit, all live lanes together
+        const Hit h = PAIRS ? closest_hit_pairs(K, PL, lane, live, ro, rd) : closest_hit<GEOM>(K, live, ro, rd, stk);
+
+        // ---- [C] first half of the shading
+        bool end_path = false, shaded = false, want_shadow = false;
+        Surface hit;
+        hit.point = hit.normal = mk3(0.0f);
+        hit.t = 0.0f;
+        hit.front_face = true;
+        f3 L = mk3(0.0f), light_scale = mk3(0.0f), shadow_o = mk3(0.0f);
+        float pdf_sample = 1.0f, shadow_tmax = 0.0f, light_att = 1.0f;
+        if (live) {
+            ++n_ext;
+            if (h.mesh < 0) {
+                if (bounce == 0 && s == 0) {
+                    first_normal = mk3(0.0f);
+                    first_depth = 1e30f;
+                    first_id = -1;
+                }
+                if (K.use_sky) { // sampleSky, gradient (render_utils.cuh:115-125)
+                    const float t = 0.5f * (rd.y + 1.0f);
+                    acc = acc + throughput * lerp(K.sky_bottom, K.sky_top, t);
+                } else {
+                    acc = acc + throughput * mk3(0.0f);
+                }
+                end_path = true;
+            } else {
+                shaded = true;
+                hit = make_surface(K, h, ro, rd, nullptr, nullptr);
+                if (bounce == 0 && s == 0) {
+                    first_normal = hit.normal;
+                    first_depth = hit.t;
+                    first_id = h.mesh;
+                }
+                const float4 m0 = K.materials[h.mesh * 6 + 0], m2 = K.materials[h.mesh * 6 + 2];
+                if (!hit.front_face) { // Beer-Lambert on back faces (path_logic.cuh:823-829)
+                    const f3 T_unit = mk3(max_(1e-6f, m0.x), max_(1e-6f, m0.y), max_(1e-6f, m0.z));
+                    const f3 absorption = mk3(-det_log(T_unit.x), -det_log(T_unit.y), -det_log(T_unit.z));
+                    throughput = throughput * beerLambert(absorption, hit.t);
+                }
+                if (m2.x > 0.0f || m2.y > 0.0f || m2.z > 0.0f) {
+                    if (bounce == 0 || prev_was_specular)
+                        acc = acc + throughput * mk3(m2.x, m2.y, m2.z);
+                }
+                // light sample of next-event estimation (path_logic.cuh:305-382, 840)
+                if (!ray_spec && K.n_lights > 0) {
+                    float r = rng_uniform(rng);
+                    r = min_(r, 0.99999994f);
+                    const int light_index = (int)(r * (float)K.n_lights);
+                    const LightRec light = load_light(K.lights, light_index);
+                    const float pdf_pick = 1.0f / (float)K.n_lights;
+                    float attenuation = 1.0f;
+                    float light_dist = 1e30f;
+                    const f3 light_radiance = light.color * light.intensity;
+                    if (light.type == 1) {
+                        L = -light.direction;
+                        pdf_sample = pdf_pick;
+                    } else {
+                        const f3 toLight = light.position - hit.point;
+                        const float light_dist_sq = dot(toLight, toLight);
+                        light_dist = __builtin_sqrtf(light_dist_sq);
+                        if (light.radius <= 0.0f) {
+                            L = toLight / light_dist;
+                            pdf_sample = pdf_pick;
+                        } else {
+                            float sin_theta_max_sq = (light.radius * light.radius) / light_dist_sq;
+                            sin_theta_max_sq = min_(sin_theta_max_sq, 0.9999f);
+                            const float cos_theta_max = __builtin_sqrtf(1.0f - sin_theta_max_sq);
+                            L = sample_cone_direction(rng, toLight / light_dist, cos_theta_max);
+                            const float solid_angle = TWO_PI_F * (1.0f - cos_theta_max);
+                            pdf_sample = (solid_angle > 1e-6f) ? (pdf_pick / solid_angle) : pdf_pick;
+                        }
+                        attenuation = attenuate(light_dist, light.range);
+                        if (light.type == 2) {
+                            const float theta = dot(L, -light.direction);
+                            const float epsilon = light.inner - light.outer;
+                            float spotIntensity;
+                            if (epsilon <= 1e-6f)
+                                spotIntensity = (theta >= light.outer) ? 1.0f : 0.0f;
+                            else
+                                spotIntensity = clampf((theta - light.outer) / epsilon, 0.0f, 1.0f);
+                            attenuation *= spotIntensity;
+                        }
+                    }
+                    const f3 shadow_offset = dot(hit.normal, L) > 0.0f ? hit.normal * 1e-4f : -hit.normal * 1e-4f;
+                    shadow_o = hit.point + shadow_offset;
+                    shadow_tmax = light_dist - 1e-3f;
+                    // bsdf * light_radiance * attenuation / pdf: the last three factors are kept apart
+                    // so the product is formed in the reference's order once visibility is known
+                    light_scale = light_radiance;
+                    light_att = attenuation;
+                    want_shadow = true;
+                    ++n_shadow;
+                }
+            }
+        }
+
+        // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas)
+        bool in_shadow = false;
+        if (__builtin_amdgcn_ballot_w64(want_shadow)) {
+            in_shadow = PAIRS ? any_hit_pairs(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
+                              : any_hit<GEOM>(K, want_shadow, shadow_o, L, shadow_tmax, stk);
+        }
+
+        // ---- [E] second half of the shading
+        if (shaded) {
+            const Material mat = load_material(K.materials, h.mesh);
+            const f3 V = -rd;
+            if (want_shadow && !in_shadow) {
+                const float attenuation = light_att;
+                const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
+                if (pdf_sample > 0.0f) {
+                    f3 direct = bsdf * light_scale * attenuation / pdf_sample;
+                    direct = clamp_vector_soft(direct, 500.0f);
+                    if (direct.x > 0.0f || direct.y > 0.0f || direct.z > 0.0f) {
+                        const float pdf_brdf = material_pdf<FULL>(hit, mat, V, L);
+                        const float wgt = mis_weight(pdf_sample, pdf_brdf);
+                        acc = acc + throughput * direct * wgt;
+                    }
+                }
+            }
+            f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
+            bool is_specular = false;
+            if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular)) {
+                end_path = true;
+            } else {
+                prev_was_specular = is_specular;
+                bool killed = false;
+                if (bounce >= 2) { // Russian roulette (path_logic.cuh:871-880)
+                    const float p = max_(0.05f, min_(0.95f, max_(throughput.x, max_(throughput.y, throughput.z))));
+                    if (rng_uniform(rng) > p)
+                        killed = true;
+                    else
+                        throughput = throughput / p;
+                }
+                if (killed) {
+                    end_path = true;
+                } else {
+                    throughput = throughput * att;
+                    throughput = clamp_vector_soft(throughput, 50.0f);
+                    const f3 off = hit.normal * 1e-4f;
+                    ro = (dot(scatter_dir, hit.normal) > 0.0f) ? (hit.point + off) : (hit.point - off);
+                    rd = scatter_dir;
+                    ray_spec = is_specular;
+                    ++bounce;
+                    if (bounce >= K.max_depth)
+                        end_path = true;
+                }
+            }
+        }
+        if (live && end_path) {
+            acc = clamp_vector_soft(acc, 100.0f);
+            avg_color = avg_color + acc;
+            ++s;
+            fresh = true;
+        }
+    }
+
+    if (inside) {
+        K.rng[idx] = rng.d;
+        K.rng[npix + idx] = rng.v0;
+        K.rng[2 * npix + idx] = rng.v1;
+        K.rng[3 * npix + idx] = rng.v2;
+        K.rng[4 * npix + idx] = rng.v3;
+        K.rng[5 * npix + idx] = rng.v4;
+        const f3 out = avg_color / (float)K.spp;
+        K.accum[idx * 3 + 0] = out.x;
+        K.accum[idx * 3 + 1] = out.y;
+        K.accum[idx * 3 + 2] = out.z;
+        K.normal[idx * 3 + 0] = first_normal.x;
+        K.normal[idx * 3 + 1] = first_normal.y;
+        K.normal[idx * 3 + 2] = first_normal.z;
+        K.depth[idx] = first_depth;
+        K.object_id[idx] = first_id;
+        // tonemap_kernel fused: RGB8, rows flipped within the tile (scene.cuh:2013-2015)
+        unsigned char r8, g8, b8;
+        tonemap_pixel(out, r8, g8, b8);
+        const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
+        K.rgb8[o + 0] = r8;
+        K.rgb8[o + 1] = g8;
+        K.rgb8[o + 2] = b8;
+    }
+    if (K.counters) {
+        uint32_t a = n_ext, b = n_shadow, c = inside ? (uint32_t)K.spp : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
+            c += __shfl_xor(c, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&K.counters[0], (unsigned long long)a);
+            atomicAdd(&K.counters[1], (unsigned long long)b);
+            atomicAdd(&K.counters[2], (unsigned long long)c);
+        }
+    }
+}
+
+} // namespace pt

@@ -7,7 +7,7 @@
 // scene, launch on the context's stream, time kernels with HIP events.
 // There is no CPU rendering path in this library.
 #include "../../include/ptrt.h"
-#include "pt_kernels.hip.h"
+#include "pt_render.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -62,6 +62,7 @@ struct ptrt_ctx {
     int tlas_root_ref = 0;
     bool tlas_single_leaf = false, all_single_leaf = false, mats_full = false;
     int stack_entries = 1;
+    int pair_meshes = 0, pair_tri_slots = 0, pair_max_leaf = 0;
     bool have_geometry = false, have_materials = false;
 
     pt::Camera cam{};
@@ -69,7 +70,7 @@ struct ptrt_ctx {
     int use_sky = 1;
 
     // options
-    int count_rays = 0, force_geom = -1, force_full = 0;
+    int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1;
     bool timed = false;
 };
 
@@ -288,6 +289,9 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.n_meshes = c->n_meshes;
     K.n_lights = c->n_lights;
     K.stack_entries = c->stack_entries;
+    K.pair_meshes = c->pair_meshes;
+    K.pair_tri_slots = c->pair_tri_slots;
+    K.pair_max_leaf = c->pair_max_leaf;
     K.cam = c->cam;
     K.sky_top = c->sky_top;
     K.sky_bottom = c->sky_bottom;
@@ -314,11 +318,21 @@ int pick_geom(ptrt_ctx *c) {
     return g;
 }
 
-template <int GEOM> void launch_trace(ptrt_ctx *c, const pt::KParams &K, bool full, int grid, size_t lds) {
+template <int GEOM, bool PAIRS> void launch_trace(ptrt_ctx *c, const pt::KParams &K, bool full, int grid, size_t lds) {
     if (full)
-        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true>), dim3(grid), dim3(64), lds, c->stream, K);
+        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PAIRS>), dim3(grid), dim3(64), lds, c->stream, K);
     else
-        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false>), dim3(grid), dim3(64), lds, c->stream, K);
+        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PAIRS>), dim3(grid), dim3(64), lds, c->stream, K);
+}
+
+// in-wave (ray, mesh) pair compaction needs every BLAS to be one leaf and the staged
+// triangle packets to fit a modest LDS budget
+size_t pair_lds_bytes(const ptrt_ctx *c) {
+    return (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * 256 + 6 * 256 + 512 + 256;
+}
+bool use_pairs(const ptrt_ctx *c, int geom) {
+    return geom == 0 && c->pair_trace && c->pair_meshes > 0 && c->pair_meshes < 65536 && c->pair_max_leaf < 65536 &&
+           pair_lds_bytes(c) <= 40 * 1024;
 }
 
 bool ctx_live(ptrt_ctx *c) {
@@ -606,6 +620,12 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     c->tlas_single_leaf = troot < 0;
     c->all_single_leaf = all_leaf;
     c->stack_entries = R.max_depth < 1 ? 1 : R.max_depth;
+    c->pair_tri_slots = (int)(R.tris.size() / 3);
+    c->pair_meshes = troot < 0 ? tleaves[~troot].y : 0;
+    c->pair_max_leaf = 0;
+    for (const int2 &lf : R.leaves)
+        if (lf.y > c->pair_max_leaf)
+            c->pair_max_leaf = lf.y;
     c->have_geometry = true;
     return PTRT_OK;
 }
@@ -733,15 +753,18 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const int grid = K.tiles_x * tiles_y;
     const int geom = pick_geom(c);
     const bool full = c->mats_full || c->force_full;
-    const size_t lds = (geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2);
+    const bool pairs = use_pairs(c, geom);
+    const size_t lds = pairs ? pair_lds_bytes(c) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
     const int slot = (int)(c->launches % EV_RING);
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
-    if (geom == 0)
-        launch_trace<0>(c, K, full, grid, lds);
+    if (pairs)
+        launch_trace<0, true>(c, K, full, grid, lds);
+    else if (geom == 0)
+        launch_trace<0, false>(c, K, full, grid, lds);
     else if (geom == 1)
-        launch_trace<1>(c, K, full, grid, lds);
+        launch_trace<1, false>(c, K, full, grid, lds);
     else
-        launch_trace<2>(c, K, full, grid, lds);
+        launch_trace<2, false>(c, K, full, grid, lds);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     c->launches++;
@@ -949,6 +972,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->force_geom = (int)value;
     } else if (n == "force_full")
         c->force_full = value ? 1 : 0;
+    else if (n == "pair_trace") // 0: lock-step mesh loop instead of (ray, mesh) pair compaction (A/B, tests)
+        c->pair_trace = value ? 1 : 0;
     else
         return fail(c, PTRT_E_INVALID, "unknown option '%s'", name);
     return PTRT_OK;

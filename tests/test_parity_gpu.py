@@ -33,6 +33,35 @@ def test_cornell_general_traversal_variants(P, O, blue_noise, force_geom):
     s.close()
 
 
+def test_cornell_lockstep_variant(P, O, blue_noise):
+    """pair_trace=0: the lock-step mesh loop (no (ray, mesh) pair compaction) gives the same bits."""
+    s = P.Scene(88, 72)
+    P.scenes.cornell(s)
+    s.set_option("pair_trace", 0)
+    gpu, cpu = render_both(P, O, s, blue_noise, 3, 4, 2)
+    assert_frames_equal(gpu, cpu)
+    s.close()
+
+
+def test_instanced_meshes(P, O, blue_noise):
+    """has_transform instances (setPosition/setRotation/scale on the instance transform), incl. the
+    reference's inverse-matrix quirk, in the single-leaf (pair) and deep-BVH kernels."""
+    for leaf in ((12, 5), (2, 0)):
+        s = P.Scene(72, 64)
+        P.scenes.cornell(s)
+        extra = s.addCube(P.Material((0.2, 0.3, 0.9), 0.4))
+        s.setPosition(extra, (1.0, -1.0, -5.0))
+        s.setRotation(extra, (0.3, 0.5, 0.1))
+        s.setInstanceScale(extra, (1.5, 0.7, 1.2))
+        ball = s.addSphere(6, P.Material((0.9, 0.9, 0.2), 0.05, 1.0))
+        s.setPosition(ball, (-2.0, 1.5, -4.0))
+        s.setBVHLeafTarget(*leaf)
+        gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
+        assert_frames_equal(gpu, cpu)
+        assert (gpu[0]["object_id"] == extra).sum() > 50
+        s.close()
+
+
 @pytest.mark.parametrize("leaf", [(1, 0), (2, 1), (4, 0)])
 def test_cornell_deep_bvh(P, O, blue_noise, leaf):
     """Small leaf targets turn every cube into a multi-level BLAS and the scene into a real TLAS."""

@@ -36,6 +36,7 @@ struct PairLds {
     float *ray;               // 6 planes of 64
     unsigned long long *best; // 64
     uint32_t *occ;            // 64
+    uint2 *stack;             // PMODE 2: [entry][lane] BLAS traversal stack
 };
 PT_DEV size_t pair_lds_bytes(int tri_slots, int meshes) {
     return (size_t)tri_slots * 48 + (size_t)meshes * 16 + (size_t)meshes * 256 + 6 * 256 + 512 + 256;
@@ -54,6 +55,8 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes) {
     l.ray = (float *)p;
     p += 6 * 256;
     l.occ = (uint32_t *)p;
+    p += 256;
+    l.stack = (uint2 *)p;
     return l;
 }
 
@@ -218,22 +221,119 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
     return occluded;
 }
 
+// PMODE 2: the same pair compaction when the BLASes are real trees (single-leaf TLAS): a lane
+// takes one (ray, mesh) pair and walks that mesh's BVH with its own LDS stack, so every lane
+// traverses SOME mesh instead of idling while the wave walks meshes its ray never touches.
+// Within a pair the traversal is the reference's (local best, strict `<`); pairs of one ray
+// merge by the same 64-bit min {t bits, mesh order | payload}.
+PT_DEV Hit closest_hit_pairs_bvh(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
+    const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
+    LdsStack stk{L.stack + lane};
+    __syncthreads();
+    for (int c = 0; c < P; c += 64) {
+        const int p = c + lane;
+        const bool valid = p < P;
+        const uint32_t e = L.pairs[valid ? p : 0];
+        const int r = (int)(e & 63u), oi = (int)(e >> 8);
+        const int4 mt = L.meshtab[oi];
+        f3 po, pd;
+        float dirScale;
+        pair_ray(K, L, r, mt, po, pd, dirScale);
+        const RayO pr = make_ray(po, pd);
+        float tb = T_FAR, ub = 0.0f, vb = 0.0f;
+        int sb = -1;
+        blas_closest<false>(K, mt.x, valid, pr, stk, tb, ub, vb, sb);
+        if (sb >= 0) {
+            const float tw = (mt.z & 1) ? tb / dirScale : tb;
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)oi << 24) | (uint32_t)sb;
+            __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    const unsigned long long key = L.best[lane];
+    __syncthreads();
+    Hit h;
+    h.u = h.v = 0.0f;
+    if (!alive || key == ~0ull) {
+        h.t = h.t_local = T_FAR;
+        h.mesh = -1;
+        h.slot = -1;
+        return h;
+    }
+    const int4 mt = L.meshtab[(int)((key >> 24) & 0xffu)];
+    h.t = __uint_as_float((uint32_t)(key >> 32));
+    h.mesh = mt.w;
+    h.slot = (int)(key & 0xffffffu);
+    h.t_local = h.t;
+    if (mt.z & 1) {
+        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
+        RayO pr;
+        pr.o = xform_point(rec[2], rec[3], rec[4], o);
+        pr.d = normalize(xform_dir(rec[2], rec[3], rec[4], d));
+        const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
+        float t, u, v;
+        tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, T_FAR, t, u, v);
+        h.t_local = t;
+    }
+    return h;
+}
+
+PT_DEV bool any_hit_pairs_bvh(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
+    const int P = build_pairs<true>(K, L, lane, alive, o, d, tMax);
+    LdsStack stk{L.stack + lane};
+    float *tmaxv = (float *)L.best;
+    tmaxv[lane] = tMax;
+    __syncthreads();
+    for (int c = 0; c < P; c += 64) {
+        const int p = c + lane;
+        const bool valid = p < P;
+        const uint32_t e = L.pairs[valid ? p : 0];
+        const int r = (int)(e & 63u), oi = (int)(e >> 8);
+        const int4 mt = L.meshtab[oi];
+        f3 po, pd;
+        float dirScale;
+        pair_ray(K, L, r, mt, po, pd, dirScale);
+        const RayO pr = make_ray(po, pd);
+        float tm = tmaxv[r];
+        if (mt.z & 1)
+            tm = tm * dirScale;
+        if (blas_any<false>(K, mt.x, valid, pr, tm, stk))
+            L.occ[r] = 1u;
+    }
+    __syncthreads();
+    const bool occluded = alive && (L.occ[lane] != 0u);
+    __syncthreads();
+    return occluded;
+}
+
 // ---------------------------------------------------------------------------------
-template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void path_trace_kernel(const KParams K) {
+#ifndef PT_WAVES_PER_EU
+#define PT_WAVES_PER_EU 3
+#endif
+// PMODE 0: lock-step mesh loop; 1: pair compaction, single-leaf BLASes (triangles staged in LDS);
+//       2: pair compaction, general BLASes (per-lane traversal, LDS stacks)
+template <int GEOM, bool FULL, int PMODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, 8))) void path_trace_kernel(const KParams K) {
     extern __shared__ uint2 lds_raw[];
     const int lane = threadIdx.x;
     LdsStack stk{lds_raw + lane};
     PairLds PL{};
-    if (PAIRS) {
-        PL = carve_pair_lds((void *)lds_raw, K.pair_tri_slots, K.pair_meshes);
-        for (int i = lane; i < K.pair_tri_slots * 3; i += 64)
+    if (PMODE) {
+        const int staged = (PMODE == 1) ? K.pair_tri_slots : 0;
+        PL = carve_pair_lds((void *)lds_raw, staged, K.pair_meshes);
+        for (int i = lane; i < staged * 3; i += 64)
             PL.tris[i] = K.tris[i];
         const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
         for (int i = lane; i < K.pair_meshes; i += 64) {
             const int m = K.tlas_mesh_ids[lf.x + i];
             const MeshHead mh = load_mesh_head(K, m);
-            const int2 leaf = K.leaves[~mh.root_ref];
-            PL.meshtab[i] = make_int4(leaf.x, leaf.y, mh.flags, m);
+            if (PMODE == 1) {
+                const int2 leaf = K.leaves[~mh.root_ref];
+                PL.meshtab[i] = make_int4(leaf.x, leaf.y, mh.flags, m);
+            } else {
+                PL.meshtab[i] = make_int4(mh.root_ref, 0, mh.flags, m);
+            }
         }
         __syncthreads();
     }
@@ -257,9 +357,6 @@ template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void
     }
 
     f3 avg_color = mk3(0.0f);
-    f3 first_normal = mk3(0.0f);
-    float first_depth = 1e30f;
-    int first_id = -1;
     uint32_t n_ext = 0, n_shadow = 0;
 
     int s = inside ? 0 : K.spp;
@@ -306,7 +403,9 @@ template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void
         }
 
         // ---- [B] closest hit, all live lanes together
-        const Hit h = PAIRS ? closest_hit_pairs(K, PL, lane, live, ro, rd) : closest_hit<GEOM>(K, live, ro, rd, stk);
+        const Hit h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd)
+                      : (PMODE == 2) ? closest_hit_pairs_bvh(K, PL, lane, live, ro, rd)
+                                     : closest_hit<GEOM>(K, live, ro, rd, stk);
 
         // ---- [C] first half of the shading
         bool end_path = false, shaded = false, want_shadow = false;
@@ -319,10 +418,12 @@ template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void
         if (live) {
             ++n_ext;
             if (h.mesh < 0) {
-                if (bounce == 0 && s == 0) {
-                    first_normal = mk3(0.0f);
-                    first_depth = 1e30f;
-                    first_id = -1;
+                if (bounce == 0 && s == 0) { // G-buffer of the first sample's first hit (scene_kernels.cuh:181-193)
+                    K.normal[idx * 3 + 0] = 0.0f;
+                    K.normal[idx * 3 + 1] = 0.0f;
+                    K.normal[idx * 3 + 2] = 0.0f;
+                    K.depth[idx] = 1e30f;
+                    K.object_id[idx] = -1;
                 }
                 if (K.use_sky) { // sampleSky, gradient (render_utils.cuh:115-125)
                     const float t = 0.5f * (rd.y + 1.0f);
@@ -335,9 +436,11 @@ template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void
                 shaded = true;
                 hit = make_surface(K, h, ro, rd, nullptr, nullptr);
                 if (bounce == 0 && s == 0) {
-                    first_normal = hit.normal;
-                    first_depth = hit.t;
-                    first_id = h.mesh;
+                    K.normal[idx * 3 + 0] = hit.normal.x;
+                    K.normal[idx * 3 + 1] = hit.normal.y;
+                    K.normal[idx * 3 + 2] = hit.normal.z;
+                    K.depth[idx] = hit.t;
+                    K.object_id[idx] = h.mesh;
                 }
                 const float4 m0 = K.materials[h.mesh * 6 + 0], m2 = K.materials[h.mesh * 6 + 2];
                 if (!hit.front_face) { // Beer-Lambert on back faces (path_logic.cuh:823-829)
@@ -405,8 +508,9 @@ template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void
         // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas)
         bool in_shadow = false;
         if (__builtin_amdgcn_ballot_w64(want_shadow)) {
-            in_shadow = PAIRS ? any_hit_pairs(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
-                              : any_hit<GEOM>(K, want_shadow, shadow_o, L, shadow_tmax, stk);
+            in_shadow = (PMODE == 1)   ? any_hit_pairs(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
+                        : (PMODE == 2) ? any_hit_pairs_bvh(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
+                                       : any_hit<GEOM>(K, want_shadow, shadow_o, L, shadow_tmax, stk);
         }
 
         // ---- [E] second half of the shading
@@ -474,11 +578,6 @@ template <int GEOM, bool FULL, bool PAIRS> __global__ __launch_bounds__(64) void
         K.accum[idx * 3 + 0] = out.x;
         K.accum[idx * 3 + 1] = out.y;
         K.accum[idx * 3 + 2] = out.z;
-        K.normal[idx * 3 + 0] = first_normal.x;
-        K.normal[idx * 3 + 1] = first_normal.y;
-        K.normal[idx * 3 + 2] = first_normal.z;
-        K.depth[idx] = first_depth;
-        K.object_id[idx] = first_id;
         // tonemap_kernel fused: RGB8, rows flipped within the tile (scene.cuh:2013-2015)
         unsigned char r8, g8, b8;
         tonemap_pixel(out, r8, g8, b8);

@@ -318,21 +318,28 @@ int pick_geom(ptrt_ctx *c) {
     return g;
 }
 
-template <int GEOM, bool PAIRS> void launch_trace(ptrt_ctx *c, const pt::KParams &K, bool full, int grid, size_t lds) {
+template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams &K, bool full, int grid, size_t lds) {
     if (full)
-        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PAIRS>), dim3(grid), dim3(64), lds, c->stream, K);
+        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE>), dim3(grid), dim3(64), lds, c->stream, K);
     else
-        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PAIRS>), dim3(grid), dim3(64), lds, c->stream, K);
+        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PMODE>), dim3(grid), dim3(64), lds, c->stream, K);
 }
 
 // in-wave (ray, mesh) pair compaction needs every BLAS to be one leaf and the staged
 // triangle packets to fit a modest LDS budget
-size_t pair_lds_bytes(const ptrt_ctx *c) {
-    return (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * 256 + 6 * 256 + 512 + 256;
+size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
+    const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * 256 + 6 * 256 + 512 + 256;
+    return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 : common + (size_t)c->stack_entries * 64 * sizeof(uint2);
 }
-bool use_pairs(const ptrt_ctx *c, int geom) {
-    return geom == 0 && c->pair_trace && c->pair_meshes > 0 && c->pair_meshes < 65536 && c->pair_max_leaf < 65536 &&
-           pair_lds_bytes(c) <= 40 * 1024;
+// 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
+int pair_mode(const ptrt_ctx *c, int geom) {
+    if (!c->pair_trace || c->pair_meshes <= 0)
+        return 0;
+    if (geom == 0 && c->pair_meshes < 65536 && c->pair_max_leaf < 65536 && pair_lds_bytes(c, 1) <= 40 * 1024)
+        return 1;
+    if (geom <= 1 && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) && pair_lds_bytes(c, 2) <= 40 * 1024)
+        return 2;
+    return 0;
 }
 
 bool ctx_live(ptrt_ctx *c) {
@@ -753,18 +760,20 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const int grid = K.tiles_x * tiles_y;
     const int geom = pick_geom(c);
     const bool full = c->mats_full || c->force_full;
-    const bool pairs = use_pairs(c, geom);
-    const size_t lds = pairs ? pair_lds_bytes(c) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
+    const int pmode = pair_mode(c, geom);
+    const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
     const int slot = (int)(c->launches % EV_RING);
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
-    if (pairs)
-        launch_trace<0, true>(c, K, full, grid, lds);
+    if (pmode == 1)
+        launch_trace<0, 1>(c, K, full, grid, lds);
+    else if (pmode == 2)
+        launch_trace<1, 2>(c, K, full, grid, lds);
     else if (geom == 0)
-        launch_trace<0, false>(c, K, full, grid, lds);
+        launch_trace<0, 0>(c, K, full, grid, lds);
     else if (geom == 1)
-        launch_trace<1, false>(c, K, full, grid, lds);
+        launch_trace<1, 0>(c, K, full, grid, lds);
     else
-        launch_trace<2, false>(c, K, full, grid, lds);
+        launch_trace<2, 0>(c, K, full, grid, lds);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     c->launches++;

@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptrt_amd.so")
+LIB_PATH = os.environ.get("PTRT_AMD_LIB") or os.path.join(_HERE, "libptrt_amd.so")  # env override: A/B builds
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `make -C ptrt-game-engine_amd` "

@@ -43,6 +43,24 @@ PT_DEV f3 operator+(f3 a, float t) { return f3{a.x + t, a.y + t, a.z + t}; }
 PT_DEV f3 operator-(f3 a, float t) { return f3{a.x - t, a.y - t, a.z - t}; }
 
 PT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// ------------------------------------------------ correctly rounded 1/y and x/y, cheaper
+// hipcc expands an IEEE fp32 division into v_div_scale x2, v_rcp, 5 FMAs, v_div_fmas, v_div_fixup
+// (11 VALU).  The scale/fixup steps only act on extreme exponents; for operands whose exponents are
+// in [2^-60, 2^60) the Newton core alone gives the same correctly rounded result:
+//   1/y : r0 = v_rcp_f32(y) (<= 1 ulp); e = fma(-y,r0,1); r = fma(e,r0,r0)             (3 VALU)
+//   x/y : q0 = x*r; q1 = fma(fma(-y,q0,x), r, q0); q = fma(fma(-y,q1,x), r, q1)          (+5 VALU)
+// tests/test_misc_gpu.py checks rcp_ieee against `1.0f/y` for EVERY fp32 bit pattern and div_ieee
+// against `x/y` on 2^32 random pairs; anything outside the guarded range takes the compiler's
+// division.  The oracle divides with the CPU's IEEE divider.
+PT_DEV bool mid_exponent(float x) { return (((__float_as_uint(x) >> 23) & 0xffu) - 67u) < 120u; }
+PT_DEV float rcp_ieee(float y) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!mid_exponent(y)) != 0ull, 0))
+        return 1.0f / y;
+    const float r0 = __builtin_amdgcn_rcpf(y);
+    const float e = fma_(-y, r0, 1.0f);
+    return fma_(e, r0, r0);
+}
 PT_DEV float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 PT_DEV f3 cross(f3 a, f3 b) {
     return f3{fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))};

@@ -127,7 +127,7 @@ PT_DEV bool slab(f3 bmin, f3 bmax, const RayO &r, float tMax, float &tEntry) {
 PT_DEV bool tri_test(f3 v0, f3 e1, f3 e2, const RayO &r, float tMax, float &t_out, float &u_out, float &v_out) {
     const f3 h = cross(r.d, e2);
     const float a = dot(e1, h);
-    const float f = 1.0f / a;
+    const float f = rcp_ieee(a);
     const f3 s = r.o - v0;
     const float u = f * dot(s, h);
     const f3 q = cross(s, e1);
@@ -946,6 +946,25 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const KParams K, const f
         r.local_point[0] = lp.x; r.local_point[1] = lp.y; r.local_point[2] = lp.z;
     }
     out[i] = r;
+}
+
+// exhaustive check of rcp_ieee: every fp32 bit pattern, against the compiler's IEEE division.
+// out[0] = number of mismatching inputs, out[1..8] = first few offending bit patterns.
+__global__ void rcp_check_kernel(unsigned int *out) {
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = tid; b < (1ull << 32); b += stride) {
+        const float y = __uint_as_float((uint32_t)b);
+        const float want = 1.0f / y;
+        const float got = rcp_ieee(y);
+        const uint32_t wu = __float_as_uint(want), gu = __float_as_uint(got);
+        const bool both_nan = (want != want) && (got != got);
+        if (wu != gu && !both_nan) {
+            const unsigned int k = atomicAdd(&out[0], 1u);
+            if (k < 8)
+                out[1 + k] = (uint32_t)b;
+        }
+    }
 }
 
 // deterministic-math probe for tests: op 0 sin, 1 cos, 2 exp, 3 log, 4 pow

@@ -988,6 +988,22 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
     return PTRT_OK;
 }
 
+// test hook: exhaustive rcp_ieee check; out9[0] = mismatches, out9[1..8] = first offending inputs
+int ptrt_debug_rcp_check(ptrt_ctx *c, unsigned int *out9) {
+    if (!ctx_live(c) || !out9)
+        return fail(c, PTRT_E_INVALID, "ptrt_debug_rcp_check: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    unsigned int *d = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d, 9 * sizeof(unsigned int)));
+    HIP_TRY(c, hipMemset(d, 0, 9 * sizeof(unsigned int)));
+    hipLaunchKernelGGL(pt::rcp_check_kernel, dim3(4096), dim3(256), 0, c->stream, d);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out9, d, 9 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return PTRT_OK;
+}
+
 // test hook (not part of the drop-in surface): the kernels' deterministic math on the GPU
 int ptrt_debug_detmath(ptrt_ctx *c, int op, const float *x, const float *y, int n, float *out) {
     if (!ctx_live(c) || !x || !out || n <= 0)

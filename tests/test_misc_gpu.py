@@ -52,6 +52,16 @@ def test_gpu_reproduces_committed_goldens(P, name):
     s.close()
 
 
+def test_fast_reciprocal_is_ieee_for_every_float(P):
+    """rcp_ieee (v_rcp_f32 + one Newton step, guarded by exponent) == 1.0f/y for all 2^32 inputs."""
+    s = P.Scene(16, 16)
+    out = (C.c_uint * 9)()
+    P.lib.ptrt_debug_rcp_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    assert P.lib.ptrt_debug_rcp_check(s.ctx, out) == 0
+    assert out[0] == 0, f"{out[0]} mismatches, first inputs: {[hex(v) for v in list(out)[1:9]]}"
+    s.close()
+
+
 def test_render_before_upload_and_bad_scenes(P):
     s = P.Scene(32, 32)
     assert P.lib.ptrt_render(s.ctx, 0, 1, 1, None, 0) == -4          # PTRT_E_NOT_READY

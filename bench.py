@@ -31,6 +31,8 @@ def build_scene(P, name, W, H, y0, rows, device):
         P.scenes.cornell(s)
     elif name == "showcase":
         P.scenes.showcase(s)
+    elif name == "fluid":
+        s.water_mesh, _ = P.scenes.fluid(s, cells=256, t=0.0)
     else:
         raise SystemExit(f"unknown scene {name}")
     s.setDenoiserEnabled(False)
@@ -47,7 +49,7 @@ def cpu_baseline(P, scene_name, W, H, spp, depth, frame, threads):
     s.setSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     desc = s.flatten()
-    rows = H if scene_name == "cornell" else max(8, H // 8)
+    rows = H if scene_name == "cornell" else max(8, H // 4)
     y0 = (H - rows) // 2
     rng = O.xorwow_init(P.DEFAULT_SEED, y0 * W, rows * W)
     bn = P.blue_noise_table()
@@ -109,7 +111,19 @@ def main():
         frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
         views = tilefarm.frame_views(frame, H, world)
 
+    # config 5 ("fluid"): every step first moves the water surface (new vertex positions already in
+    # HBM), refits the BVH on the GPU, then traces: the refit+trace pipeline, no host sync inside
+    water = None
+    if args.scene == "fluid":
+        import numpy as np
+        water = [torch.from_numpy(np.ascontiguousarray(P.scenes.water_vertices(256, t / 60.0))).cuda()
+                 for t in range(8)]
+    counter = [0]
+
     def step():
+        if water is not None:
+            scene.refitFromDevice(scene.water_mesh, water[counter[0] % len(water)].data_ptr())
+            counter[0] += 1
         scene.render_to_device(tile.data_ptr())
         tilefarm.gather_bands(dist, tile, views, rank, world, H)
 

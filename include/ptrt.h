@@ -210,6 +210,20 @@ int ptrt_set_camera(ptrt_ctx *ctx, const ptrt_camera *cam);
 /* Scene::setSkyGradient / disableSky (scene.cuh:1548-1565). */
 int ptrt_set_sky(ptrt_ctx *ctx, const ptrt_vec3 *top, const ptrt_vec3 *bottom, int use_sky);
 
+/* Dynamic geometry, same topology (the `Triangles` path of updatePTScene,
+ * src/common/PTRTtransfer.cuh:2249-2270, followed by Scene::commitObjectChanges,
+ * scene.cuh:1784).  The reference re-allocates the mesh's device arrays and REBUILDS its BVH on
+ * the CPU every frame (mesh.cuh:330-346,403-516); here the new vertex positions of mesh
+ * `mesh_index` are copied into the arena (`verts`: vert_count x 3 floats, a DEVICE pointer if
+ * verts_on_device != 0) and ptrt_refit() re-derives, on the GPU and on the context's stream,
+ * the triangle packets, every leaf and inner box of the dirty meshes (bottom-up over the
+ * UNCHANGED tree), the mesh root boxes and the TLAS root box.  No host synchronisation.
+ * Requires a single-leaf TLAS (<= leaf-target+tol meshes).  A refitted tree has the boxes a
+ * host refit of the same topology gives (min/max are exact), so results stay bit-comparable
+ * with the oracle run on those arrays; it is NOT the tree a fresh median-split build would give. */
+int ptrt_update_vertices(ptrt_ctx *ctx, int mesh_index, const float *verts, int vert_count, int verts_on_device);
+int ptrt_refit(ptrt_ctx *ctx);
+
 /* convenience: the five uploads above from one flattened description */
 int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);
 

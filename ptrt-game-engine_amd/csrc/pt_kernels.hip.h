@@ -62,8 +62,8 @@ struct KParams {
     const float4 *materials; // 6 float4 per mesh
     const float4 *lights;    // 4 float4 per light
     const float2 *blue_noise; // 64*64
-    float tlas_root_min[3], tlas_root_max[3];
-    int tlas_root_ref; // >=0 inner node, <0 ~leaf
+    const float4 *tlas_root_box; // {bmin, bmax} of TLAS node 0, in device memory so ptrt_refit can move it
+    int tlas_root_ref;           // >=0 inner node, <0 ~leaf
     int n_meshes, n_lights;
     int stack_entries; // LDS stack depth per lane (BLAS)
     // pair-compacted tracing (pt_render.hip.h), valid when every BLAS is a single leaf
@@ -88,6 +88,15 @@ struct KParams {
 
 constexpr int MESH_REC_F4 = 12;
 constexpr float T_FAR = 1e30f;
+
+PT_DEV f3 tlas_bmin(const KParams &K) {
+    const float4 a = K.tlas_root_box[0];
+    return mk3(a.x, a.y, a.z);
+}
+PT_DEV f3 tlas_bmax(const KParams &K) {
+    const float4 a = K.tlas_root_box[1];
+    return mk3(a.x, a.y, a.z);
+}
 
 struct RayO { // RayOptimized, intersection.cuh:39-88
     f3 o, d, inv;
@@ -431,8 +440,8 @@ template <int GEOM> PT_DEV Hit closest_hit(const KParams &K, bool alive, f3 o, f
     best.slot = -1;
     const RayO w = make_ray(o, d);
     float tE;
-    alive = alive && slab(mk3(K.tlas_root_min[0], K.tlas_root_min[1], K.tlas_root_min[2]),
-                          mk3(K.tlas_root_max[0], K.tlas_root_max[1], K.tlas_root_max[2]), w, T_FAR, tE);
+    alive = alive && slab(tlas_bmin(K),
+                          tlas_bmax(K), w, T_FAR, tE);
     if (GEOM < 2) {
         const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
         for (int i = 0; i < lf.y; ++i)
@@ -484,8 +493,8 @@ template <int GEOM> PT_DEV Hit closest_hit(const KParams &K, bool alive, f3 o, f
 template <int GEOM> PT_DEV bool any_hit(const KParams &K, bool alive, f3 o, f3 d, float tMax, LdsStack stk) {
     const RayO w = make_ray(o, d);
     float tE;
-    alive = alive && slab(mk3(K.tlas_root_min[0], K.tlas_root_min[1], K.tlas_root_min[2]),
-                          mk3(K.tlas_root_max[0], K.tlas_root_max[1], K.tlas_root_max[2]), w, tMax, tE);
+    alive = alive && slab(tlas_bmin(K),
+                          tlas_bmax(K), w, tMax, tE);
     bool found = false;
     if (GEOM < 2) {
         const int2 lf = K.tlas_leaves[~K.tlas_root_ref];

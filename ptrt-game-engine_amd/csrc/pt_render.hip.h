@@ -69,8 +69,7 @@ template <bool ANY>
 PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
     const RayO w = make_ray(o, d);
     float tE;
-    alive = alive && slab(mk3(K.tlas_root_min[0], K.tlas_root_min[1], K.tlas_root_min[2]),
-                          mk3(K.tlas_root_max[0], K.tlas_root_max[1], K.tlas_root_max[2]), w, ANY ? tMax : T_FAR, tE);
+    alive = alive && slab(tlas_bmin(K), tlas_bmax(K), w, ANY ? tMax : T_FAR, tE);
     L.ray[0 * 64 + lane] = o.x;
     L.ray[1 * 64 + lane] = o.y;
     L.ray[2 * 64 + lane] = o.z;

@@ -7,6 +7,7 @@
 // scene, launch on the context's stream, time kernels with HIP events.
 // There is no CPU rendering path in this library.
 #include "../../include/ptrt.h"
+#include "pt_refit.hip.h"
 #include "pt_render.hip.h"
 
 #include <hip/hip_runtime.h>
@@ -58,8 +59,17 @@ struct ptrt_ctx {
     std::vector<float4> h_mesh_recs;
     std::vector<unsigned char> h_shadow_skip; // per material: transmission > 0.5
     int n_meshes = 0, n_materials = 0, n_lights = 0;
-    float tlas_root_min[3] = {0, 0, 0}, tlas_root_max[3] = {0, 0, 0};
+    float4 *d_tlas_root_box = nullptr; // {bmin, bmax}
     int tlas_root_ref = 0;
+    // refit support (ptrt_update_vertices / ptrt_refit)
+    float *d_verts = nullptr;       // all meshes' vertices, xyz packed
+    int4 *d_slot_face = nullptr;    // per leaf slot: global vertex indices + face index
+    int *d_leaf_dst = nullptr;      // per leaf: where its box is stored (see convert_tree)
+    int *d_node_dst = nullptr;      // per inner node: where its own box is stored
+    int *d_level_nodes = nullptr;   // inner nodes ordered by depth
+    std::vector<int> level_offset;  // level_offset[d] .. level_offset[d+1]: nodes at depth d+1
+    std::vector<int> mesh_vert_base, mesh_vert_count;
+    int n_slots = 0, n_leaves = 0;
     bool tlas_single_leaf = false, all_single_leaf = false, mats_full = false;
     int stack_entries = 1;
     int pair_meshes = 0, pair_tri_slots = 0, pair_max_leaf = 0;
@@ -174,9 +184,13 @@ struct Relayout {
 // Converts one reference-shaped tree (pre-order 40-byte nodes) into child-pair nodes.
 // `emit_leaf(start,count)` returns the leaf id for a leaf node.  Returns the root
 // reference, or INT32_MIN on malformed input.
+// `dst` codes say where a subtree's box is stored, for the GPU refit: >= 0 -> inner node
+// (code >> 1), side (code & 1); < 0 -> root box of tree `root_dst`.  `emit_leaf(start,count,dst)`.
+// `node_dst`/`node_depth` (optional) receive that code and the depth of every inner node created.
 template <class EmitLeaf>
 int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nodes, EmitLeaf emit_leaf, int &max_depth,
-                 std::string &why) {
+                 std::string &why, int root_dst = -1, std::vector<int> *node_dst = nullptr,
+                 std::vector<int> *node_depth = nullptr) {
     struct Item {
         int old_idx, new_idx, depth;
     };
@@ -185,9 +199,9 @@ int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nod
         return INT32_MIN;
     }
     std::vector<char> seen((size_t)n_in, 0);
-    auto ref_of = [&](int old_idx, int depth, std::vector<Item> &work) -> int {
+    auto ref_of = [&](int old_idx, int depth, int dst, std::vector<Item> &work) -> int {
         if (old_idx < 0)
-            return ~emit_leaf(0, 0); // absent child: an empty leaf behind an unhittable box
+            return ~emit_leaf(0, 0, dst); // absent child: an empty leaf behind an unhittable box
         if (old_idx >= n_in) {
             why = "child index out of range";
             return INT32_MIN;
@@ -199,14 +213,20 @@ int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nod
         seen[old_idx] = 1;
         const ptrt_bvh_node &N = in[old_idx];
         if (N.count > 0)
-            return ~emit_leaf(N.start, N.count);
+            return ~emit_leaf(N.start, N.count, dst);
         const int ni = (int)(out_nodes.size() / 4);
         out_nodes.resize(out_nodes.size() + 4);
+        if (node_dst) {
+            node_dst->resize((size_t)ni + 1, 0);
+            node_depth->resize((size_t)ni + 1, 0);
+            (*node_dst)[ni] = dst;
+            (*node_depth)[ni] = depth + 1;
+        }
         work.push_back({old_idx, ni, depth + 1});
         return ni;
     };
     std::vector<Item> work;
-    const int root = ref_of(0, 0, work);
+    const int root = ref_of(0, 0, root_dst, work);
     if (root == INT32_MIN)
         return root;
     while (!work.empty()) {
@@ -215,10 +235,10 @@ int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nod
         if (it.depth > max_depth)
             max_depth = it.depth;
         const ptrt_bvh_node &N = in[it.old_idx];
-        const int L = ref_of(N.left, it.depth, work);
+        const int L = ref_of(N.left, it.depth, it.new_idx * 2, work);
         if (L == INT32_MIN)
             return L;
-        const int R = ref_of(N.right, it.depth, work);
+        const int R = ref_of(N.right, it.depth, it.new_idx * 2 + 1, work);
         if (R == INT32_MIN)
             return R;
         const float BIG = 1e30f;
@@ -248,20 +268,33 @@ void free_scene(ptrt_ctx *c) {
     dfree(c->d_leaves);
     dfree(c->d_tlas_leaves);
     dfree(c->d_tlas_mesh_ids);
+    dfree(c->d_tlas_root_box);
+    dfree(c->d_verts);
+    dfree(c->d_slot_face);
+    dfree(c->d_leaf_dst);
+    dfree(c->d_node_dst);
+    dfree(c->d_level_nodes);
 }
 
-int push_mesh_recs(ptrt_ctx *c) {
-    // flags bit1 (skipped by shadow rays) comes from the materials; re-applied on either upload
-    std::vector<float4> recs = c->h_mesh_recs;
+// flags bit1 (skipped by shadow rays) comes from the materials; re-applied on either upload.
+// `full` re-sends the whole records (geometry upload); otherwise only the flag words are patched
+// so that boxes moved by ptrt_refit on the device are not overwritten with stale host copies.
+int push_mesh_recs(ptrt_ctx *c, bool full) {
     for (int m = 0; m < c->n_meshes; ++m) {
         int flags;
-        std::memcpy(&flags, &recs[(size_t)m * pt::MESH_REC_F4 + 1].w, 4);
+        std::memcpy(&flags, &c->h_mesh_recs[(size_t)m * pt::MESH_REC_F4 + 1].w, 4);
         flags &= ~2;
         if (m < (int)c->h_shadow_skip.size() && c->h_shadow_skip[m])
             flags |= 2;
-        recs[(size_t)m * pt::MESH_REC_F4 + 1].w = as_f(flags);
+        c->h_mesh_recs[(size_t)m * pt::MESH_REC_F4 + 1].w = as_f(flags);
     }
-    return upload(c, c->d_mesh_recs, recs);
+    if (full)
+        return upload(c, c->d_mesh_recs, c->h_mesh_recs);
+    for (int m = 0; m < c->n_meshes; ++m)
+        HIP_TRY(c, hipMemcpyAsync(&c->d_mesh_recs[(size_t)m * pt::MESH_REC_F4 + 1].w,
+                                  &c->h_mesh_recs[(size_t)m * pt::MESH_REC_F4 + 1].w, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTRT_OK;
 }
 
 int set_device(ptrt_ctx *c) {
@@ -281,10 +314,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.materials = c->d_materials;
     K.lights = c->d_lights;
     K.blue_noise = c->d_blue;
-    for (int k = 0; k < 3; ++k) {
-        K.tlas_root_min[k] = c->tlas_root_min[k];
-        K.tlas_root_max[k] = c->tlas_root_max[k];
-    }
+    K.tlas_root_box = c->d_tlas_root_box;
     K.tlas_root_ref = c->tlas_root_ref;
     K.n_meshes = c->n_meshes;
     K.n_lights = c->n_lights;
@@ -519,6 +549,10 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     std::vector<float4> recs((size_t)mesh_count * pt::MESH_REC_F4, f4(0, 0, 0, 0));
     bool all_leaf = true;
     std::string why;
+    // refit bookkeeping
+    std::vector<float> all_verts;
+    std::vector<int4> slot_face;
+    std::vector<int> leaf_dst, node_dst, node_depth, vert_base(mesh_count), vert_count(mesh_count);
     for (int m = 0; m < mesh_count; ++m) {
         const ptrt_mesh_desc &M = meshes[m];
         if (!M.verts || !M.faces || !M.nodes || !M.prim_indices || M.node_count <= 0 || M.face_count <= 0 ||
@@ -530,22 +564,29 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
                 t.v2 >= M.vert_count)
                 return fail(c, PTRT_E_INVALID, "mesh %d: face %d references a vertex out of range", m, f);
         }
+        vert_base[m] = (int)(all_verts.size() / 3);
+        vert_count[m] = M.vert_count;
+        all_verts.insert(all_verts.end(), &M.verts[0].x, &M.verts[0].x + (size_t)M.vert_count * 3);
+        const int vb = vert_base[m];
         bool bad = false;
-        auto emit_leaf = [&](int start, int count) -> int {
+        auto emit_leaf = [&](int start, int count, int dst) -> int {
             const int id = (int)R.leaves.size();
             if (count > 0 && (start < 0 || start + count > M.prim_count)) {
                 bad = true;
                 count = 0;
             }
             R.leaves.push_back(make_int2((int)(R.tris.size() / 3), count));
+            leaf_dst.push_back(dst);
             for (int i = 0; i < count; ++i) {
                 const int fidx = M.prim_indices[start + i];
                 if (fidx < 0 || fidx >= M.face_count) {
                     bad = true;
                     R.tris.insert(R.tris.end(), 3, f4(0, 0, 0, 0));
+                    slot_face.push_back(make_int4(vb, vb, vb, 0));
                     continue;
                 }
                 const ptrt_tri &t = M.faces[fidx];
+                slot_face.push_back(make_int4(vb + t.v0, vb + t.v1, vb + t.v2, fidx));
                 const ptrt_vec3 &a = M.verts[t.v0], &b = M.verts[t.v1], &d = M.verts[t.v2];
                 // e1 = v1 - v0, e2 = v2 - v0: the same fp32 subtractions the reference performs per
                 // test (intersection.cuh:224-225), done once here
@@ -556,7 +597,7 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
             return id;
         };
         int depth = 0;
-        const int root = convert_tree(M.nodes, M.node_count, R.nodes, emit_leaf, depth, why);
+        const int root = convert_tree(M.nodes, M.node_count, R.nodes, emit_leaf, depth, why, -(m + 1), &node_dst, &node_depth);
         if (root == INT32_MIN || bad)
             return fail(c, PTRT_E_INVALID, "mesh %d: malformed BVH (%s)", m, bad ? "leaf range out of bounds" : why.c_str());
         if (depth > 23)
@@ -581,7 +622,7 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     std::vector<float4> tnodes;
     std::vector<int2> tleaves;
     bool bad = false;
-    auto emit_tleaf = [&](int start, int count) -> int {
+    auto emit_tleaf = [&](int start, int count, int) -> int {
         if (count > 0 && (start < 0 || start + count > tlas_index_count)) {
             bad = true;
             count = 0;
@@ -603,8 +644,51 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     free_scene(c);
     c->n_meshes = mesh_count;
     c->h_mesh_recs = recs;
-    if (int rc = push_mesh_recs(c))
+    if (int rc = push_mesh_recs(c, true))
         return rc;
+    {
+        // inner nodes grouped by depth (deepest last) for the level-by-level refit
+        node_dst.resize(R.nodes.size() / 4, 0);
+        node_depth.resize(R.nodes.size() / 4, 0);
+        int maxd = 0;
+        for (int d : node_depth)
+            if (d > maxd)
+                maxd = d;
+        c->level_offset.assign((size_t)maxd + 1, 0);
+        for (int d : node_depth)
+            if (d >= 1)
+                c->level_offset[d]++;
+        // level_offset[d] currently holds the count of depth d (index 0 unused); prefix-sum it
+        int run = 0;
+        for (int d = 1; d <= maxd; ++d) {
+            const int n = c->level_offset[d];
+            c->level_offset[d - 1] = run;
+            run += n;
+        }
+        c->level_offset[maxd] = run;
+        std::vector<int> fill(c->level_offset.begin(), c->level_offset.end()), level_nodes((size_t)run);
+        for (int i = 0; i < (int)node_depth.size(); ++i)
+            if (node_depth[i] >= 1)
+                level_nodes[(size_t)fill[node_depth[i] - 1]++] = i;
+        std::vector<float4> rootbox = {f4(tlas_nodes[0].bmin.x, tlas_nodes[0].bmin.y, tlas_nodes[0].bmin.z, 0.0f),
+                                       f4(tlas_nodes[0].bmax.x, tlas_nodes[0].bmax.y, tlas_nodes[0].bmax.z, 0.0f)};
+        if (int rc = upload(c, c->d_tlas_root_box, rootbox))
+            return rc;
+        if (int rc = upload(c, c->d_verts, all_verts))
+            return rc;
+        if (int rc = upload(c, c->d_slot_face, slot_face))
+            return rc;
+        if (int rc = upload(c, c->d_leaf_dst, leaf_dst))
+            return rc;
+        if (int rc = upload(c, c->d_node_dst, node_dst))
+            return rc;
+        if (int rc = upload(c, c->d_level_nodes, level_nodes))
+            return rc;
+        c->mesh_vert_base = vert_base;
+        c->mesh_vert_count = vert_count;
+        c->n_slots = (int)slot_face.size();
+        c->n_leaves = (int)R.leaves.size();
+    }
     if (int rc = upload(c, c->d_nodes, R.nodes))
         return rc;
     if (int rc = upload(c, c->d_leaves, R.leaves))
@@ -617,12 +701,6 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
         return rc;
     if (int rc = upload(c, c->d_tlas_mesh_ids, tids))
         return rc;
-    c->tlas_root_min[0] = tlas_nodes[0].bmin.x;
-    c->tlas_root_min[1] = tlas_nodes[0].bmin.y;
-    c->tlas_root_min[2] = tlas_nodes[0].bmin.z;
-    c->tlas_root_max[0] = tlas_nodes[0].bmax.x;
-    c->tlas_root_max[1] = tlas_nodes[0].bmax.y;
-    c->tlas_root_max[2] = tlas_nodes[0].bmax.z;
     c->tlas_root_ref = troot;
     c->tlas_single_leaf = troot < 0;
     c->all_single_leaf = all_leaf;
@@ -669,7 +747,7 @@ int ptrt_upload_materials(ptrt_ctx *c, const ptrt_materials *m) {
     c->mats_full = full;
     c->have_materials = true;
     if (c->have_geometry)
-        return push_mesh_recs(c);
+        return push_mesh_recs(c, false);
     return PTRT_OK;
 }
 
@@ -717,6 +795,51 @@ int ptrt_set_sky(ptrt_ctx *c, const ptrt_vec3 *top, const ptrt_vec3 *bottom, int
     if (bottom)
         c->sky_bottom = pt::f3{bottom->x, bottom->y, bottom->z};
     c->use_sky = use_sky ? 1 : 0;
+    return PTRT_OK;
+}
+
+int ptrt_update_vertices(ptrt_ctx *c, int mesh, const float *verts, int vert_count, int on_device) {
+    if (!ctx_live(c) || !verts)
+        return fail(c, PTRT_E_INVALID, "ptrt_update_vertices: bad argument");
+    if (!c->have_geometry)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_update_vertices: geometry not uploaded");
+    if (mesh < 0 || mesh >= c->n_meshes || vert_count != c->mesh_vert_count[mesh])
+        return fail(c, PTRT_E_INVALID, "ptrt_update_vertices: mesh %d has %d vertices, got %d (topology must not change)",
+                    mesh, (mesh >= 0 && mesh < c->n_meshes) ? c->mesh_vert_count[mesh] : -1, vert_count);
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_verts + (size_t)c->mesh_vert_base[mesh] * 3, verts, (size_t)vert_count * 12,
+                              on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!on_device)
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller may reuse its host buffer
+    return PTRT_OK;
+}
+
+int ptrt_refit(ptrt_ctx *c) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_refit: bad context");
+    if (!c->have_geometry)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_refit: geometry not uploaded");
+    if (!c->tlas_single_leaf)
+        return fail(c, PTRT_E_INVALID, "ptrt_refit: needs a single-leaf TLAS; rebuild and re-upload instead");
+    if (int rc = set_device(c))
+        return rc;
+    const int B = 256;
+    if (c->n_slots > 0)
+        hipLaunchKernelGGL(pt::repack_tris_kernel, dim3((c->n_slots + B - 1) / B), dim3(B), 0, c->stream, c->d_verts,
+                           c->d_slot_face, c->d_tris, c->n_slots);
+    if (c->n_leaves > 0)
+        hipLaunchKernelGGL(pt::refit_leaves_kernel, dim3((c->n_leaves + B - 1) / B), dim3(B), 0, c->stream, c->d_verts,
+                           c->d_slot_face, c->d_leaves, c->d_leaf_dst, c->d_nodes, c->d_mesh_recs, c->n_leaves);
+    for (int d = (int)c->level_offset.size() - 1; d >= 1; --d) { // depth d nodes: [offset[d-1], offset[d])
+        const int begin = c->level_offset[d - 1], count = c->level_offset[d] - begin;
+        if (count > 0)
+            hipLaunchKernelGGL(pt::refit_level_kernel, dim3((count + B - 1) / B), dim3(B), 0, c->stream,
+                               c->d_level_nodes + begin, count, c->d_node_dst, c->d_nodes, c->d_mesh_recs);
+    }
+    hipLaunchKernelGGL(pt::refit_tlas_root_kernel, dim3(1), dim3(64), 0, c->stream, c->d_mesh_recs, c->d_tlas_leaves,
+                       c->d_tlas_mesh_ids, c->tlas_root_ref, c->d_tlas_root_box);
+    HIP_TRY(c, hipGetLastError());
     return PTRT_OK;
 }
 

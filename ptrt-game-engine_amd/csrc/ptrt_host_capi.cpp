@@ -220,6 +220,11 @@ int hs_set_mesh_material(void *s, int mesh, const float *mat27) {
 
 int hs_upload(void *s) { HS_TRY(static_cast<Scene *>(s)->uploadToGPU()); return 0; }
 int hs_commit_object_changes(void *s) { HS_TRY(static_cast<Scene *>(s)->commitObjectChanges()); return 0; }
+int hs_refit_object_changes(void *s) { HS_TRY(static_cast<Scene *>(s)->refitObjectChanges()); return 0; }
+int hs_refit_from_device(void *s, int mesh, const void *device_xyz) {
+    HS_TRY(static_cast<Scene *>(s)->refitFromDevice((size_t)mesh, static_cast<const float *>(device_xyz)));
+    return 0;
+}
 int hs_render_to_device(void *s, void *device_pixels) {
     HS_TRY(static_cast<Scene *>(s)->render_to_device(static_cast<unsigned char *>(device_pixels)));
     return 0;

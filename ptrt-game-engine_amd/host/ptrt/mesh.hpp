@@ -180,6 +180,34 @@ class Mesh {
         bvhDirty = false;
     }
 
+    // Refit (NOT in the reference, which rebuilds every dirty mesh: mesh.cuh:403-492): keep the
+    // tree and the leaf assignment, recompute every box from the current vertices.  Nodes are in
+    // pre-order (children after parents), so one reverse sweep is bottom-up.  The GPU refit
+    // (csrc/pt_refit.hip.h) produces the same boxes bit for bit: min/max are exact.
+    void refitBVH() {
+        for (int i = (int)bvhNodes.size() - 1; i >= 0; --i) {
+            DeviceBVHNode &n = bvhNodes[i];
+            AABB b = AABB::make_invalid();
+            if (n.count > 0) {
+                for (int k = 0; k < n.count; ++k) {
+                    const Tri &t = faces[bvhPrimIndices[n.start + k]];
+                    b.expand(vertices[t.v0]);
+                    b.expand(vertices[t.v1]);
+                    b.expand(vertices[t.v2]);
+                }
+            } else {
+                for (int ch : {n.left, n.right})
+                    if (ch >= 0) {
+                        const DeviceBVHNode &c = bvhNodes[ch];
+                        b.expand(AABB{vec3(c.bmin.x, c.bmin.y, c.bmin.z), vec3(c.bmax.x, c.bmax.y, c.bmax.z)});
+                    }
+            }
+            n.bmin = {b.bmin.x, b.bmin.y, b.bmin.z};
+            n.bmax = {b.bmax.x, b.bmax.y, b.bmax.z};
+        }
+        bvhDirty = false;
+    }
+
     AABB boundingBox() const { // mesh.cuh:526-541
         if (vertices.empty())
             return {vec3(0.0f), vec3(0.0f)};

@@ -406,6 +406,40 @@ class Scene {
     void scaleMesh(size_t i, float s) { if (Mesh *m = getMesh(i)) m->scale(s); }
     void scaleMesh(size_t i, const vec3 &s) { if (Mesh *m = getMesh(i)) m->scale(s); }
     void commitObjectChanges() { updateAccelerationStructures(); resetAccumulation(); } // scene.cuh:1784
+    // Dynamic geometry with unchanged topology (the fluid-sim caller, PTRTtransfer.cuh:2249-2270):
+    // instead of commitObjectChanges()' full CPU rebuild, keep every tree and refit its boxes --
+    // on the host copy (so flatten() stays consistent) and on the GPU (ptrt_update_vertices +
+    // ptrt_refit, no re-upload of the arena).  Not in the reference.
+    void refitObjectChanges() {
+        needBackend();
+        if (!gpu_resources_initialized || geometryDirty)
+            throw std::runtime_error("refitObjectChanges: call uploadToGPU() first (topology must already be on the GPU)");
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            Mesh *m = meshes[i].get();
+            if (!m->vertsDirty)
+                continue;
+            m->refitBVH();
+            m->vertsDirty = false;
+            check(ptrt_update_vertices(ctx, (int)i, &m->vertices[0].x, (int)m->vertices.size(), 0),
+                  "Failed to update vertices");
+        }
+        check(ptrt_refit(ctx), "Failed to refit");
+        buildTLAS(); // host copy of the (single-node) TLAS box
+        flat.tlas_nodes = h_tlasNodes.data();
+        resetAccumulation();
+    }
+    // same, the new positions already being in device memory (no host copy is kept: flatten()
+    // then describes the LAST host-side vertices)
+    void refitFromDevice(size_t mesh, const float *device_xyz) {
+        needBackend();
+        Mesh *m = getMesh(mesh);
+        if (!m)
+            throw std::runtime_error("refitFromDevice: no such mesh");
+        check(ptrt_update_vertices(ctx, (int)mesh, device_xyz, (int)m->vertices.size(), 1), "Failed to update vertices");
+        check(ptrt_refit(ctx), "Failed to refit");
+        resetAccumulation();
+    }
+
     bool hasObjectChanges() const {
         for (auto &m : meshes)
             if (m->bvhDirty)

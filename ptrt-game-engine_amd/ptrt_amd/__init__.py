@@ -177,6 +177,10 @@ _sig("hs_get_settings", None, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POI
 _sig("hs_set_mesh_material", C.c_int, _vp, C.c_int, _fp)
 _sig("hs_upload", C.c_int, _vp)
 _sig("hs_commit_object_changes", C.c_int, _vp)
+_sig("hs_refit_object_changes", C.c_int, _vp)
+_sig("hs_refit_from_device", C.c_int, _vp, C.c_int, _vp)
+_sig("ptrt_update_vertices", C.c_int, _vp, C.c_int, _fp, C.c_int, C.c_int)
+_sig("ptrt_refit", C.c_int, _vp)
 _sig("hs_render_to_device", C.c_int, _vp, _vp)
 _sig("hs_render_to_host", C.c_int, _vp, _vp)
 _sig("hs_get_frame_count", C.c_int, _vp)
@@ -341,6 +345,14 @@ class Scene:
     def initBlueNoise(self): self._chk(lib.hs_init_blue_noise(self._h))
     def uploadToGPU(self): self._chk(lib.hs_upload(self._h))
     def commitObjectChanges(self): self._chk(lib.hs_commit_object_changes(self._h))
+
+    def refitObjectChanges(self):
+        """Dynamic vertices, same topology: host + GPU BVH refit instead of the reference's rebuild."""
+        self._chk(lib.hs_refit_object_changes(self._h))
+
+    def refitFromDevice(self, mesh, device_ptr):
+        """New vertex positions (n x 3 float32) already in device memory -> update + GPU refit, no host sync."""
+        self._chk(lib.hs_refit_from_device(self._h, mesh, C.c_void_p(device_ptr)))
     def getFrameCount(self): return lib.hs_get_frame_count(self._h)
     def setFrameCount(self, f): lib.hs_set_frame_count(self._h, f)
 

@@ -1,0 +1,91 @@
+"""Dynamic geometry (BASELINE config 5): host refit invariants on CPU, GPU refit parity on the box."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import assert_frames_equal, render_both
+
+
+def node_boxes(P, d, m):
+    M = d.contents.meshes[m]
+    return np.ctypeslib.as_array(C.cast(M.nodes, C.POINTER(C.c_float)), (M.node_count, 10))[:, :6].copy()
+
+
+def test_host_refit_of_unchanged_vertices_is_the_built_tree(P):
+    s = P.Scene(32, 32, device=P.HOST_ONLY)
+    w, ship = P.scenes.fluid(s, cells=24, t=0.0, ship_segments=10)
+    d = s.flatten()
+    before = [node_boxes(P, d, m) for m in (w, ship)]
+    tl = d.contents.tlas_nodes[0]
+    t_before = (tl.bmin.x, tl.bmin.y, tl.bmin.z, tl.bmax.x, tl.bmax.y, tl.bmax.z)
+    # moving the vertices and moving them back must restore every box bit for bit
+    v0 = P.scenes.water_vertices(24, 0.0)
+    s.setVertices(w, P.scenes.water_vertices(24, 0.7))
+    with pytest.raises(P.PtrtError):
+        s.refitObjectChanges()          # host-only scene: no back end, fails loudly
+    s.setVertices(w, v0)
+    d2 = s.flatten()                    # (rebuild path: same vertices -> same tree)
+    for m, b in zip((w, ship), before):
+        assert np.array_equal(node_boxes(P, d2, m).view(np.uint32), b.view(np.uint32))
+    tl = d2.contents.tlas_nodes[0]
+    assert (tl.bmin.x, tl.bmin.y, tl.bmin.z, tl.bmax.x, tl.bmax.y, tl.bmax.z) == t_before
+
+
+@pytest.mark.gpu
+def test_gpu_refit_matches_oracle_on_host_refit(P, O, blue_noise):
+    s = P.Scene(96, 64)
+    w, ship = P.scenes.fluid(s, cells=24, t=0.0, ship_segments=10)
+    gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 1)
+    assert_frames_equal(gpu, cpu)
+    base_ids = gpu[0]["object_id"].copy()
+    for step, t in enumerate((0.4, 1.1)):
+        s.setVertices(w, P.scenes.water_vertices(24, t))
+        s.refitObjectChanges()
+        assert s.getFrameCount() == 0
+        s.reset_rng(P.DEFAULT_SEED)
+        rng = O.xorwow_init(P.DEFAULT_SEED, 0, 96 * 64)
+        rgb = s.render_to_host()
+        c = O.render(s.flatten(), 96, 64, 2, 4, 0, blue_noise, rng, threads=8)
+        assert np.array_equal(s.read(P.BUF_OBJECT_ID), c["object_id"])
+        assert np.array_equal(s.read(P.BUF_ACCUM).view(np.uint32), c["accum"].view(np.uint32))
+        assert np.array_equal(s.read(P.BUF_DEPTH).view(np.uint32), c["depth"].view(np.uint32))
+        assert np.array_equal(s.read(P.BUF_RNG), rng)
+        assert np.array_equal(rgb, O.tonemap(c["accum"], 96, 64))
+        assert not np.array_equal(s.read(P.BUF_DEPTH), gpu[0]["depth"])      # the surface did move
+    # refit vs the reference's behaviour (full rebuild of the moved mesh): same first hits but for ties
+    refit_ids, refit_depth = s.read(P.BUF_OBJECT_ID), s.read(P.BUF_DEPTH)
+    r = P.Scene(96, 64)
+    P.scenes.fluid(r, cells=24, t=1.1, ship_segments=10)
+    g2, _ = render_both(P, O, r, blue_noise, 2, 4, 1)
+    assert (g2[0]["object_id"] == refit_ids).mean() > 0.999
+    assert np.allclose(g2[0]["depth"], refit_depth, rtol=1e-5, atol=1e-5) or \
+        (np.abs(g2[0]["depth"] - refit_depth) < 1e-4).mean() > 0.999
+    s.close()
+    r.close()
+
+
+@pytest.mark.gpu
+def test_refit_from_device_memory(P, O, blue_noise):
+    import torch
+    s = P.Scene(64, 48)
+    w, ship = P.scenes.fluid(s, cells=16, t=0.0, ship_segments=8)
+    gpu, cpu = render_both(P, O, s, blue_noise, 1, 3, 1)
+    assert_frames_equal(gpu, cpu)
+    v = P.scenes.water_vertices(16, 0.9)
+    s.setVertices(w, v)
+    s.refitObjectChanges()
+    s.reset_rng(P.DEFAULT_SEED)
+    a = s.render_to_host().copy()
+    acc_a = s.read(P.BUF_ACCUM).copy()
+    # same positions, this time handed over as a device buffer after wrecking them on the GPU first
+    junk = torch.from_numpy(np.ascontiguousarray(P.scenes.water_vertices(16, 3.3))).cuda()
+    s.refitFromDevice(w, junk.data_ptr())
+    good = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    s.refitFromDevice(w, good.data_ptr())
+    s.reset_rng(P.DEFAULT_SEED)
+    b = s.render_to_host()
+    assert np.array_equal(a, b) and np.array_equal(acc_a.view(np.uint32), s.read(P.BUF_ACCUM).view(np.uint32))
+    # wrong vertex count is rejected
+    assert P.lib.ptrt_update_vertices(s.ctx, w, good.data_ptr() and None, 7, 1) == -1
+    s.close()

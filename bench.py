@@ -105,11 +105,14 @@ def main():
     stream = torch.cuda.current_stream()
     scene.set_stream(stream.cuda_stream)
 
-    tile = torch.empty((rows, W, 3), dtype=torch.uint8, device="cuda")
-    views = None
+    # two band images + two assembled frames: frame i's gather (RCCL's own stream) overlaps frame
+    # i+1's render; a buffer is reused only after its gather has completed
+    tiles = [torch.empty((rows, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    views = [None, None]
     if world > 1 and rank == 0:
-        frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
-        views = tilefarm.frame_views(frame, H, world)
+        frames = [torch.empty((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        views = [tilefarm.frame_views(f, H, world) for f in frames]
+    pending = [None, None]
 
     # config 5 ("fluid"): every step first moves the water surface (new vertex positions already in
     # HBM), refits the BVH on the GPU, then traces: the refit+trace pipeline, no host sync inside
@@ -118,16 +121,24 @@ def main():
         import numpy as np
         water = [torch.from_numpy(np.ascontiguousarray(P.scenes.water_vertices(256, t / 60.0))).cuda()
                  for t in range(8)]
-    counter = [0]
+    counter = [0, 0]
 
     def step():
         if water is not None:
             scene.refitFromDevice(scene.water_mesh, water[counter[0] % len(water)].data_ptr())
             counter[0] += 1
-        scene.render_to_device(tile.data_ptr())
-        tilefarm.gather_bands(dist, tile, views, rank, world, H)
+        b = counter[1] & 1
+        counter[1] += 1
+        if pending[b] is not None:
+            pending[b].wait()
+        scene.render_to_device(tiles[b].data_ptr())
+        pending[b] = tilefarm.gather_bands(dist, tiles[b], views[b], rank, world, H, async_op=True)
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -203,44 +203,14 @@ PT_DEV void blas_closest(const KParams &K, int root_ref, bool alive, const RayO 
         }
         return;
     }
+    // "while-while" traversal: all lanes first descend through inner nodes until each holds a
+    // leaf (or has no work left), THEN the wave tests leaves together, so the two code paths are
+    // not serialised against each other every step (the per-lane order of visits is unchanged)
     int cur = root_ref;
     int sp = 0;
     bool active = alive;
-    while (active) {
-        if (cur >= 0) {
-            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
-                         n3 = K.nodes[cur * 4 + 3];
-            float tL, tR;
-            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), r, tbest, tL);
-            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), r, tbest, tR);
-            const int L = __float_as_int(n3.x), R = __float_as_int(n3.y);
-            if (hL || hR) {
-                const bool nearL = hL && (!hR || tL <= tR);
-                const int nearRef = nearL ? L : R;
-                const int farRef = nearL ? R : L;
-                const bool hitFar = nearL ? hR : hL;
-                if (hitFar) {
-                    stk.push(sp, farRef, nearL ? tR : tL);
-                    ++sp;
-                }
-                cur = nearRef;
-                continue;
-            }
-        } else {
-            const int2 lf = K.leaves[~cur];
-            for (int i = 0; i < lf.y; ++i) {
-                const int slot = lf.x + i;
-                const float4 p0 = K.tris[slot * 3 + 0], p1 = K.tris[slot * 3 + 1], p2 = K.tris[slot * 3 + 2];
-                float t, u, v;
-                if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, tbest, t, u, v)) {
-                    tbest = t;
-                    ub = u;
-                    vb = v;
-                    slotb = slot;
-                }
-            }
-        }
-        // pop the next subtree that can still contain a closer hit (E1)
+    // the next subtree that can still contain a closer hit (E1)
+    auto pop = [&]() {
         active = false;
         while (sp > 0) {
             --sp;
@@ -252,6 +222,52 @@ PT_DEV void blas_closest(const KParams &K, int root_ref, bool alive, const RayO 
                 active = true;
                 break;
             }
+        }
+    };
+    while (active) {
+        while (active && cur >= 0) {
+            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
+                         n3 = K.nodes[cur * 4 + 3];
+            float tL, tR;
+            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), r, tbest, tL);
+            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), r, tbest, tR);
+            const int L = __float_as_int(n3.x), R = __float_as_int(n3.y);
+            if (hL || hR) {
+                const bool nearL = hL && (!hR || tL <= tR);
+                if (nearL ? hR : hL) {
+                    stk.push(sp, nearL ? R : L, nearL ? tR : tL);
+                    ++sp;
+                }
+                cur = nearL ? L : R;
+            } else {
+                pop();
+            }
+        }
+        if (active) { // cur is a leaf
+            const int2 lf = K.leaves[~cur];
+            // software-pipelined: packet i+1 is in flight while packet i is tested
+            const float4 *tp = K.tris + (size_t)lf.x * 3;
+            float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+            if (lf.y > 0) { // (an absent child's placeholder leaf is empty and owns no packet)
+                p0 = tp[0];
+                p1 = tp[1];
+                p2 = tp[2];
+            }
+            for (int i = 0; i < lf.y; ++i) {
+                const int nx = (i + 1 < lf.y) ? (i + 1) : i;
+                const float4 q0 = tp[nx * 3 + 0], q1 = tp[nx * 3 + 1], q2 = tp[nx * 3 + 2];
+                float t, u, v;
+                if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, tbest, t, u, v)) {
+                    tbest = t;
+                    ub = u;
+                    vb = v;
+                    slotb = lf.x + i;
+                }
+                p0 = q0;
+                p1 = q1;
+                p2 = q2;
+            }
+            pop();
         }
     }
 }

@@ -38,14 +38,12 @@ struct PairLds {
     uint32_t *occ;            // 64
     uint2 *stack;             // PMODE 2: [entry][lane] BLAS traversal stack
 };
-PT_DEV size_t pair_lds_bytes(int tri_slots, int meshes) {
-    return (size_t)tri_slots * 48 + (size_t)meshes * 16 + (size_t)meshes * 256 + 6 * 256 + 512 + 256;
-}
+constexpr int PAIR_PAD = 2; // float4 of padding in front of each mesh's packets in LDS (bank spreading)
 PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes) {
     PairLds l;
     char *p = (char *)base;
     l.tris = (float4 *)p;
-    p += (size_t)tri_slots * 48;
+    p += tri_slots ? ((size_t)tri_slots * 48 + (size_t)meshes * PAIR_PAD * 16) : 0;
     l.meshtab = (int4 *)p;
     p += (size_t)meshes * 16;
     l.best = (unsigned long long *)p;
@@ -137,7 +135,9 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
         int bi = -1;
         for (int i = 0; i < K.pair_max_leaf; ++i) {
             const int slot = mt.x + (i < mt.y ? i : 0);
-            const float4 p0 = L.tris[slot * 3 + 0], p1 = L.tris[slot * 3 + 1], p2 = L.tris[slot * 3 + 2];
+            const float4 *tp = L.tris + slot * 3 + oi * PAIR_PAD;
+            const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+            asm volatile("" ::"v"(p0.w), "v"(p1.w), "v"(p2.w)); // keep the loads ds_read_b128 (b96 is half rate)
             float t, u, v;
             const bool ok = tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tb, t, u, v);
             if (ok && i < mt.y) {
@@ -174,7 +174,8 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
         RayO pr;
         pr.o = xform_point(rec[2], rec[3], rec[4], o);
         pr.d = normalize(xform_dir(rec[2], rec[3], rec[4], d));
-        const float4 p0 = L.tris[h.slot * 3 + 0], p1 = L.tris[h.slot * 3 + 1], p2 = L.tris[h.slot * 3 + 2];
+        const float4 *tp = L.tris + h.slot * 3 + oi * PAIR_PAD;
+        const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
         float t, u, v;
         tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, T_FAR, t, u, v);
         h.t_local = t;
@@ -206,7 +207,9 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
         bool found = false;
         for (int i = 0; i < K.pair_max_leaf; ++i) {
             const int slot = mt.x + (i < mt.y ? i : 0);
-            const float4 p0 = L.tris[slot * 3 + 0], p1 = L.tris[slot * 3 + 1], p2 = L.tris[slot * 3 + 2];
+            const float4 *tp = L.tris + slot * 3 + oi * PAIR_PAD;
+            const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+            asm volatile("" ::"v"(p0.w), "v"(p1.w), "v"(p2.w)); // keep the loads ds_read_b128 (b96 is half rate)
             float t, u, v;
             const bool ok = tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tm, t, u, v);
             found |= ok && (i < mt.y);
@@ -321,9 +324,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     if (PMODE) {
         const int staged = (PMODE == 1) ? K.pair_tri_slots : 0;
         PL = carve_pair_lds((void *)lds_raw, staged, K.pair_meshes);
-        for (int i = lane; i < staged * 3; i += 64)
-            PL.tris[i] = K.tris[i];
         const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+        if (PMODE == 1) {
+            // mesh i's packets start 2*i float4 (32 B) later than in the arena: with 48-B packets
+            // the per-mesh blocks would otherwise sit a multiple of 16 banks apart and lanes working
+            // on different meshes would collide on ds_read_b128 (PAIR_PAD)
+            for (int i = 0; i < K.pair_meshes; ++i) {
+                const int m = K.tlas_mesh_ids[lf.x + i];
+                const int2 leaf = K.leaves[~__float_as_int(K.mesh_recs[m * MESH_REC_F4].w)];
+                for (int k = lane; k < leaf.y * 3; k += 64)
+                    PL.tris[leaf.x * 3 + i * PAIR_PAD + k] = K.tris[leaf.x * 3 + k];
+            }
+        }
         for (int i = lane; i < K.pair_meshes; i += 64) {
             const int m = K.tlas_mesh_ids[lf.x + i];
             const MeshHead mh = load_mesh_head(K, m);

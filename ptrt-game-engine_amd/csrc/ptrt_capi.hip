@@ -359,7 +359,8 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
 // triangle packets to fit a modest LDS budget
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
     const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * 256 + 6 * 256 + 512 + 256;
-    return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 : common + (size_t)c->stack_entries * 64 * sizeof(uint2);
+    return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
+                      : common + (size_t)c->stack_entries * 64 * sizeof(uint2);
 }
 // 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
 int pair_mode(const ptrt_ctx *c, int geom) {

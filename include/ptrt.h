@@ -163,7 +163,9 @@ enum {
     PTRT_BUF_DEPTH = 2,     /* float[rows*W]    first-hit t,      getDepthBuffer  (scene.cuh:1724)         */
     PTRT_BUF_OBJECT_ID = 3, /* int32[rows*W]    first-hit mesh index (scene_kernels.cuh:193)               */
     PTRT_BUF_RGB8 = 4,      /* uint8[rows*W*3]  tonemapped tile, bottom-up WITHIN the tile                 */
-    PTRT_BUF_RNG = 5        /* uint32[rows*W*6] generator state {d, v0..v4} per pixel (canonical order)     */
+    PTRT_BUF_RNG = 5,       /* uint32[rows*W*6] generator state {d, v0..v4} per pixel (canonical order)     */
+    PTRT_BUF_DENOISED = 6,  /* float[H*W*3]     denoiser output (d_denoised_buffer, scene.cuh:1121); denoiser on */
+    PTRT_BUF_MOTION = 7     /* float[H*W*2]     uv motion vectors, Scene::getMotionVectorBuffer (scene.cuh:1725)  */
 };
 
 typedef struct ptrt_ctx ptrt_ctx;
@@ -223,6 +225,32 @@ int ptrt_set_sky(ptrt_ctx *ctx, const ptrt_vec3 *top, const ptrt_vec3 *bottom, i
  * with the oracle run on those arrays; it is NOT the tree a fresh median-split build would give. */
 int ptrt_update_vertices(ptrt_ctx *ctx, int mesh_index, const float *verts, int vert_count, int verts_on_device);
 int ptrt_refit(ptrt_ctx *ctx);
+
+/* ---- post-process "next" row: motion vectors + spatiotemporal denoiser ----
+ * DenoiserSettings of the non-split path (src/pathtracer/rendering/denoiser.cuh:36-73); the
+ * defaults are the reference's diffuse_* values. */
+typedef struct ptrt_denoiser_settings {
+    float tau, min_alpha, max_history, sigma_luminance, sigma_normal, sigma_depth;
+    int32_t atrous_iterations;
+    float clamp_scale, firefly_threshold;
+    float depth_reject_absolute, depth_reject_relative, normal_reject_threshold, sky_depth_threshold;
+    float edge_depth_threshold, edge_normal_threshold;
+    int32_t use_object_ids, enable_firefly_suppression;
+} ptrt_denoiser_settings;
+void ptrt_denoiser_default_settings(ptrt_denoiser_settings *out);
+
+/* `new Denoiser(settings)` (denoiser.cuh:808-845; created in Scene::updateScaledBuffers,
+ * scene.cuh:1978-1993): allocates history + scratch images, marks the next frame as the first.
+ * While enabled, ptrt_render runs motion_vector_kernel (denoiser_kernels.cuh:33) with the matrix
+ * given to ptrt_set_prev_view_proj, then Denoiser::denoise (denoiser.cuh:966-1064, non-split
+ * path), and tonemaps the DENOISED image (scene.cuh:1103-1127,1204).  Full-frame contexts only
+ * (the filters read up to 32 pixels across band borders).  settings == NULL: defaults. */
+int ptrt_denoiser_enable(ptrt_ctx *ctx, const ptrt_denoiser_settings *settings);
+/* Denoiser::destroy + delete (scene.cuh:1970-1976) */
+int ptrt_denoiser_disable(ptrt_ctx *ctx);
+/* Scene::prev_view_proj (scene.cuh:113,1208,1282): proj*view of the PREVIOUS frame, 16 floats as
+ * mat4 stores them (column-major), consumed by the next ptrt_render's motion-vector pass. */
+int ptrt_set_prev_view_proj(ptrt_ctx *ctx, const float *m16);
 
 /* convenience: the five uploads above from one flattened description */
 int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);

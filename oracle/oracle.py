@@ -131,6 +131,69 @@ def any_hit(scene_desc_ptr, origins, directions, tmax):
     return out
 
 
+class DenoiserSettings(C.Structure):
+    """DenoiserSettings, non-split subset (denoiser.cuh:36-73); defaults = the diffuse_* channel."""
+    _fields_ = [("tau", C.c_float), ("min_alpha", C.c_float), ("max_history", C.c_float),
+                ("sigma_luminance", C.c_float), ("sigma_normal", C.c_float), ("sigma_depth", C.c_float),
+                ("atrous_iterations", C.c_int32), ("clamp_scale", C.c_float), ("firefly_threshold", C.c_float),
+                ("depth_reject_absolute", C.c_float), ("depth_reject_relative", C.c_float),
+                ("normal_reject_threshold", C.c_float), ("sky_depth_threshold", C.c_float),
+                ("edge_depth_threshold", C.c_float), ("edge_normal_threshold", C.c_float),
+                ("use_object_ids", C.c_int32), ("enable_firefly_suppression", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__(0.06, 0.05, 32.0, 4.0, 64.0, 0.5, 5, 1.2, 3.0, 0.1, 0.005, 0.95, 1e9, 0.01, 0.95, 1, 1)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class _DenoiserState(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("first_frame", C.c_int32),
+                ("history_mean", _fp), ("history_m2", _fp), ("history_length", _fp),
+                ("history_normal", _fp), ("history_depth", _fp), ("history_object_id", C.POINTER(C.c_int32))]
+
+
+lib.oracle_motion_vectors.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, _fp]
+lib.oracle_denoise.argtypes = [C.POINTER(DenoiserSettings), C.POINTER(_DenoiserState), _fp, _fp, _fp, _fp,
+                               C.POINTER(C.c_int32), _fp]
+
+
+class Denoiser:
+    """`class Denoiser` (denoiser.cuh:781-1070), non-split path, state held in numpy arrays."""
+
+    def __init__(self, width, height, settings=None):
+        self.w, self.h = width, height
+        self.settings = settings or DenoiserSettings()
+        n = width * height
+        self.hmean, self.hm2 = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        self.hlen, self.hdepth = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self.hnormal, self.hobj = np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        self.state = _DenoiserState(width, height, 1, _f(self.hmean), _f(self.hm2), _f(self.hlen), _f(self.hnormal),
+                                    _f(self.hdepth), self.hobj.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def denoise(self, color, normal, depth, motion, object_id):
+        color, normal = np.ascontiguousarray(color, np.float32), np.ascontiguousarray(normal, np.float32)
+        depth, motion = np.ascontiguousarray(depth, np.float32), np.ascontiguousarray(motion, np.float32)
+        oid = np.ascontiguousarray(object_id, np.int32)
+        out = np.zeros((self.w * self.h, 3), np.float32)
+        lib.oracle_denoise(C.byref(self.settings), C.byref(self.state), _f(color), _f(normal), _f(depth), _f(motion),
+                           oid.ctypes.data_as(C.POINTER(C.c_int32)), _f(out))
+        return out
+
+
+def motion_vectors(depth, width, height, camera, prev_view_proj):
+    """motion_vector_kernel; `camera` = ptrt_camera-like with origin/lower_left_corner/horizontal/vertical."""
+    cam = np.array([camera.origin.x, camera.origin.y, camera.origin.z,
+                    camera.lower_left_corner.x, camera.lower_left_corner.y, camera.lower_left_corner.z,
+                    camera.horizontal.x, camera.horizontal.y, camera.horizontal.z,
+                    camera.vertical.x, camera.vertical.y, camera.vertical.z], np.float32)
+    d = np.ascontiguousarray(depth, np.float32)
+    pvp = np.ascontiguousarray(prev_view_proj, np.float32)
+    out = np.zeros((width * height, 2), np.float32)
+    lib.oracle_motion_vectors(_f(d), width, height, _f(cam), _f(pvp), _f(out))
+    return out
+
+
 def detmath(op, x, y=None):
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)

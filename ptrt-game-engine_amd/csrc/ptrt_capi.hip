@@ -7,6 +7,7 @@
 // scene, launch on the context's stream, time kernels with HIP events.
 // There is no CPU rendering path in this library.
 #include "../../include/ptrt.h"
+#include "pt_denoise.hip.h"
 #include "pt_refit.hip.h"
 #include "pt_render.hip.h"
 
@@ -78,6 +79,18 @@ struct ptrt_ctx {
     pt::Camera cam{};
     pt::f3 sky_top{0.6f, 0.7f, 1.0f}, sky_bottom{1.0f, 1.0f, 1.0f};
     int use_sky = 1;
+
+    // denoiser (class Denoiser, denoiser.cuh:781-1070): scratch + double-buffered history
+    bool dn_on = false, dn_first = true;
+    pt::DenoiseSettings dn{};
+    float *dn_ping = nullptr, *dn_pong = nullptr, *dn_var[2] = {nullptr, nullptr};
+    float *dn_hmean[2] = {nullptr, nullptr}, *dn_hm2[2] = {nullptr, nullptr}, *dn_hlen[2] = {nullptr, nullptr};
+    float *dn_hnormal = nullptr, *dn_hdepth = nullptr;
+    int *dn_hobj = nullptr;
+    float *dn_motion = nullptr, *dn_out = nullptr, *dn_pvp = nullptr;
+    int dn_cur = 0; // which history set holds the latest result
+    int dn_active = 1, mv_active = 1;
+    float prev_view_proj[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1;
@@ -378,6 +391,72 @@ bool ctx_live(ptrt_ctx *c) {
     return c && g_live.count(c);
 }
 
+void free_denoiser(ptrt_ctx *c) {
+    dfree(c->dn_ping);
+    dfree(c->dn_pong);
+    for (int k = 0; k < 2; ++k) {
+        dfree(c->dn_var[k]);
+        dfree(c->dn_hmean[k]);
+        dfree(c->dn_hm2[k]);
+        dfree(c->dn_hlen[k]);
+    }
+    dfree(c->dn_hnormal);
+    dfree(c->dn_hdepth);
+    dfree(c->dn_hobj);
+    dfree(c->dn_motion);
+    dfree(c->dn_out);
+    dfree(c->dn_pvp);
+    c->dn_on = false;
+}
+
+// motion vectors -> Denoiser::denoise (non-split) -> tonemap of the denoised image, all on the
+// context's stream (Scene::render_to_device, scene.cuh:1103-1127,1204).  History hand-over is a
+// swap of the double-buffered sets; only the G-buffer history is copied (20 B/px).
+int run_denoiser(ptrt_ctx *c, unsigned char *rgb8) {
+    const int W = c->W, H = c->H;
+    const dim3 grid((W + 63) / 64, (H + 3) / 4), block(256);
+    const size_t n = c->npix;
+    const pt::DenoiseSettings &S = c->dn;
+    if (c->mv_active) { // perfSettings.enableMotionVectors (scene.cuh:1103); otherwise the last vectors are reused
+        HIP_TRY(c, hipMemcpyAsync(c->dn_pvp, c->prev_view_proj, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pt::motion_vector_kernel, grid, block, 0, c->stream, c->dn_motion, c->d_depth, W, H,
+                           c->cam.origin, c->cam.llc, c->cam.horizontal, c->cam.vertical, c->dn_pvp);
+    }
+    hipLaunchKernelGGL(pt::firefly_kernel, grid, block, 0, c->stream, c->dn_ping, c->d_accum, c->d_depth, c->d_normal,
+                       S.sky_depth_threshold, W, H, S.enable_firefly_suppression);
+    const int prev = c->dn_cur, next = c->dn_cur ^ 1;
+    hipLaunchKernelGGL(pt::temporal_kernel, grid, block, 0, c->stream, c->dn_hmean[next], c->dn_hm2[next], c->dn_hlen[next],
+                       c->dn_ping, c->dn_hmean[prev], c->dn_hm2[prev], c->dn_hlen[prev], c->dn_motion, c->d_depth,
+                       c->dn_hdepth, c->d_normal, c->dn_hnormal, c->d_object_id, c->dn_hobj, S, c->dn_first ? 1 : 0, W, H);
+    c->dn_cur = next;
+    hipLaunchKernelGGL(pt::variance_kernel, grid, block, 0, c->stream, c->dn_var[0], c->dn_hmean[next], c->dn_hm2[next],
+                       c->dn_hlen[next], c->d_depth, c->d_normal, c->d_object_id, S.sky_depth_threshold, S.use_object_ids, W, H);
+    const int steps[5] = {1, 2, 4, 8, 16};
+    const int iters = S.atrous_iterations < 5 ? (S.atrous_iterations < 0 ? 0 : S.atrous_iterations) : 5;
+    const float *in = c->dn_hmean[next];
+    const float *vin = c->dn_var[0];
+    for (int i = 0; i < iters; ++i) {
+        // a-trous reads the accumulated mean in place on its first pass, then ping-pongs two scratch images;
+        // the last pass writes the denoised output directly
+        float *out = (i == iters - 1) ? c->dn_out : ((i & 1) ? c->dn_pong : c->dn_ping);
+        float *vout = c->dn_var[(i + 1) & 1];
+        hipLaunchKernelGGL(pt::atrous_kernel, grid, block, 0, c->stream, out, vout, in, vin, c->d_normal, c->d_depth,
+                           c->d_object_id, steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
+                           S.edge_normal_threshold, S.use_object_ids, W, H);
+        in = out;
+        vin = vout;
+    }
+    if (iters == 0)
+        HIP_TRY(c, hipMemcpyAsync(c->dn_out, in, n * 12, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(pt::tonemap_kernel, grid, block, 0, c->stream, rgb8, c->dn_out, W, H);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->dn_hnormal, c->d_normal, n * 12, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->dn_hdepth, c->d_depth, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->dn_hobj, c->d_object_id, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    c->dn_first = false;
+    return PTRT_OK;
+}
+
 } // namespace
 
 // =====================================================================================
@@ -483,6 +562,7 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_counters);
     dfree(c->d_blue);
     dfree(c->d_jump);
+    free_denoiser(c);
     for (auto &ev : c->ev_ring)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -859,6 +939,70 @@ int ptrt_upload_scene(ptrt_ctx *c, const ptrt_scene_desc *s) {
     return ptrt_set_sky(c, &s->sky_top, &s->sky_bottom, s->use_sky);
 }
 
+void ptrt_denoiser_default_settings(ptrt_denoiser_settings *s) {
+    if (!s)
+        return;
+    // DenoiserSettings defaults, diffuse_* channel (denoiser.cuh:40-72)
+    *s = ptrt_denoiser_settings{0.06f, 0.05f, 32.0f, 4.0f, 64.0f, 0.5f, 5,    1.2f, 3.0f,
+                                0.1f,  0.005f, 0.95f, 1e9f, 0.01f, 0.95f, 1,  1};
+}
+
+int ptrt_denoiser_enable(ptrt_ctx *c, const ptrt_denoiser_settings *s) {
+    static_assert(sizeof(ptrt_denoiser_settings) == sizeof(pt::DenoiseSettings), "settings mirror");
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_denoiser_enable: bad context");
+    if (c->rows != c->H || c->y0 != 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_denoiser_enable: the denoiser needs a full-frame context (its filters "
+                                       "read across band borders); denoise on the presenting rank instead");
+    if (int rc = set_device(c))
+        return rc;
+    ptrt_denoiser_settings d;
+    ptrt_denoiser_default_settings(&d);
+    if (s)
+        d = *s;
+    free_denoiser(c);
+    std::memcpy(&c->dn, &d, sizeof d);
+    const size_t n = c->npix;
+    HIP_TRY(c, hipMalloc((void **)&c->dn_ping, n * 12));
+    HIP_TRY(c, hipMalloc((void **)&c->dn_pong, n * 12));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(c, hipMalloc((void **)&c->dn_var[k], n * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->dn_hmean[k], n * 12));
+        HIP_TRY(c, hipMalloc((void **)&c->dn_hm2[k], n * 12));
+        HIP_TRY(c, hipMalloc((void **)&c->dn_hlen[k], n * 4));
+    }
+    HIP_TRY(c, hipMalloc((void **)&c->dn_hnormal, n * 12));
+    HIP_TRY(c, hipMalloc((void **)&c->dn_hdepth, n * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->dn_hobj, n * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->dn_motion, n * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->dn_out, n * 12));
+    HIP_TRY(c, hipMalloc((void **)&c->dn_pvp, 16 * sizeof(float)));
+    HIP_TRY(c, hipMemsetAsync(c->dn_out, 0, n * 12, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dn_motion, 0, n * 8, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->dn_cur = 0;
+    c->dn_first = true;
+    c->dn_on = true;
+    return PTRT_OK;
+}
+
+int ptrt_denoiser_disable(ptrt_ctx *c) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_denoiser_disable: bad context");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_denoiser(c);
+    return PTRT_OK;
+}
+
+int ptrt_set_prev_view_proj(ptrt_ctx *c, const float *m16) {
+    if (!ctx_live(c) || !m16)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_prev_view_proj: bad argument");
+    std::memcpy(c->prev_view_proj, m16, sizeof c->prev_view_proj);
+    return PTRT_OK;
+}
+
 int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
     if (!ctx_live(c))
         return fail(c, PTRT_E_INVALID, "ptrt_render: bad context");
@@ -902,6 +1046,10 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     c->launches++;
     c->timed = true;
+    if (c->dn_on && c->dn_active) {
+        if (int rc = run_denoiser(c, K.rgb8))
+            return rc;
+    }
     if (out_rgb8 && !out_is_device) {
         HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -971,6 +1119,8 @@ void *ptrt_device_buffer(ptrt_ctx *c, int kind) {
     case PTRT_BUF_DEPTH: return c->d_depth;
     case PTRT_BUF_OBJECT_ID: return c->d_object_id;
     case PTRT_BUF_RGB8: return c->last_rgb8;
+    case PTRT_BUF_DENOISED: return c->dn_on ? c->dn_out : nullptr;
+    case PTRT_BUF_MOTION: return c->dn_on ? c->dn_motion : nullptr;
     default: return nullptr;
     }
 }
@@ -989,6 +1139,13 @@ int ptrt_read_buffer(ptrt_ctx *c, int kind, void *dst, size_t bytes) {
     case PTRT_BUF_OBJECT_ID: need = c->npix * 4; src = c->d_object_id; break;
     case PTRT_BUF_RGB8: need = c->npix * 3; src = c->last_rgb8; break;
     case PTRT_BUF_RNG: need = c->npix * 24; break;
+    case PTRT_BUF_DENOISED:
+    case PTRT_BUF_MOTION:
+        if (!c->dn_on)
+            return fail(c, PTRT_E_NOT_READY, "ptrt_read_buffer: the denoiser is not enabled");
+        need = c->npix * (kind == PTRT_BUF_DENOISED ? 12 : 8);
+        src = kind == PTRT_BUF_DENOISED ? c->dn_out : c->dn_motion;
+        break;
     default: return fail(c, PTRT_E_INVALID, "ptrt_read_buffer: unknown kind %d", kind);
     }
     if (bytes < need)
@@ -1107,6 +1264,10 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->force_full = value ? 1 : 0;
     else if (n == "pair_trace") // 0: lock-step mesh loop instead of (ray, mesh) pair compaction (A/B, tests)
         c->pair_trace = value ? 1 : 0;
+    else if (n == "denoiser_active") // perfSettings.enableDenoiser: use the (already allocated) denoiser or not
+        c->dn_active = value ? 1 : 0;
+    else if (n == "motion_vectors") // perfSettings.enableMotionVectors
+        c->mv_active = value ? 1 : 0;
     else
         return fail(c, PTRT_E_INVALID, "unknown option '%s'", name);
     return PTRT_OK;

@@ -218,6 +218,11 @@ int hs_set_mesh_material(void *s, int mesh, const float *mat27) {
     return 0;
 }
 
+// which: 0 = proj*view of the previous frame (what the next render's motion pass uses), 1 = current
+void hs_get_view_proj(void *s, int which, float *out16) {
+    const mat4 m = which ? static_cast<Scene *>(s)->getViewProjMatrix() : static_cast<Scene *>(s)->getPrevViewProjMatrix();
+    std::memcpy(out16, m.m, sizeof m.m);
+}
 int hs_upload(void *s) { HS_TRY(static_cast<Scene *>(s)->uploadToGPU()); return 0; }
 int hs_commit_object_changes(void *s) { HS_TRY(static_cast<Scene *>(s)->commitObjectChanges()); return 0; }
 int hs_refit_object_changes(void *s) { HS_TRY(static_cast<Scene *>(s)->refitObjectChanges()); return 0; }

@@ -63,6 +63,32 @@ struct mat4 {
         m[0] = m[5] = m[10] = m[15] = 1.0f;
     }
     static mat4 identity() { return mat4(); }
+    // right-handed view matrix, column-major (mat4.cuh:143-163)
+    static mat4 lookAt(const vec3 &eye, const vec3 &center, const vec3 &up) {
+        const vec3 f = normalize(center - eye);
+        const vec3 s = normalize(cross(f, up));
+        const vec3 u = cross(s, f);
+        mat4 r;
+        r.m[0] = s.x; r.m[4] = s.y; r.m[8] = s.z;
+        r.m[1] = u.x; r.m[5] = u.y; r.m[9] = u.z;
+        r.m[2] = -f.x; r.m[6] = -f.y; r.m[10] = -f.z;
+        r.m[12] = -dot(s, eye);
+        r.m[13] = -dot(u, eye);
+        r.m[14] = dot(f, eye);
+        return r;
+    }
+    // right-handed perspective projection (mat4.cuh:168-195)
+    static mat4 perspective(float fov_y_radians, float aspect, float zNear, float zFar) {
+        mat4 r;
+        const float t = tanf(fov_y_radians / 2.0f);
+        std::memset(r.m, 0, sizeof r.m);
+        r.m[0] = 1.0f / (aspect * t);
+        r.m[5] = 1.0f / (t);
+        r.m[10] = -(zFar + zNear) / (zFar - zNear);
+        r.m[11] = -1.0f;
+        r.m[14] = -(2.0f * zFar * zNear) / (zFar - zNear);
+        return r;
+    }
     mat4 transpose() const {
         mat4 r;
         for (int c = 0; c < 4; ++c)

@@ -51,9 +51,15 @@ struct Light {
 // ---- Camera (scene/camera.cuh:32-205, ray-generation state only) ----------------------
 class Camera {
     vec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
-    float lens_radius = 0.0f, fov = 90.0f, aspect = 1.0f;
+    float lens_radius = 0.0f, fov = 90.0f, aspect = 1.0f, near_clip = 0.1f, far_clip = 1000.0f;
+    mat4 view_matrix, proj_matrix; // for motion vectors (camera.cuh:41-43,88-95)
 
+    void update_matrices(const vec3 &lookfrom, const vec3 &lookat, const vec3 &vup) {
+        view_matrix = mat4::lookAt(lookfrom, lookat, vup);
+        proj_matrix = mat4::perspective(fov * (PI / 180.0f), aspect, near_clip, far_clip);
+    }
     void rebuild(const vec3 &lookat, const vec3 &vup, float focus_dist) {
+        update_matrices(origin, lookat, vup);
         w = (origin - lookat).normalized();
         u = cross(vup, w).normalized();
         v = cross(w, u);
@@ -68,10 +74,12 @@ class Camera {
 
   public:
     Camera(vec3 lookfrom, vec3 lookat, vec3 vup, float vfov, float aspect_ratio, float aperture = 0.0f,
-           float focus_dist = 1.0f, float = 0.1f, float = 1000.0f) {
+           float focus_dist = 1.0f, float znear = 0.1f, float zfar = 1000.0f) {
         origin = lookfrom;
         fov = vfov;
         aspect = aspect_ratio;
+        near_clip = znear;
+        far_clip = zfar;
         rebuild(lookat, vup, focus_dist);
         lens_radius = aperture / 2.0f;
     }
@@ -85,7 +93,12 @@ class Camera {
         v = vec3(0, 1, 0);
         w = vec3(0, 0, 1);
         aspect = aspect_ratio;
+        fov = 90.0f;
+        near_clip = 0.1f;
+        far_clip = 100.0f;
+        update_matrices(origin, vec3(0, 0, -1), vec3(0, 1, 0));
     }
+    mat4 get_view_proj() const { return proj_matrix * view_matrix; } // camera.cuh:257-259
     vec3 get_origin() const { return origin; }
     vec3 get_lower_left_corner() const { return lower_left_corner; }
     vec3 get_horizontal() const { return horizontal; }
@@ -215,6 +228,13 @@ class Scene {
             throw std::runtime_error(msg);
         }
         check(ptrt_reset_rng(ctx, PTRT_DEFAULT_SEED), "Failed to init rand states"); // scene.cuh:433-456
+        if (tileRows == h && tile_y0 == 0) {
+            // `denoiser_ = new Denoiser(settings)` (scene.cuh:1984-1993): exists from construction,
+            // used while perfSettings.enableDenoiser; band contexts cannot denoise (filters cross bands)
+            check(ptrt_denoiser_enable(ctx, nullptr), "Failed to create denoiser");
+            denoiserAllocated = true;
+        }
+        prev_view_proj = camera.get_view_proj();
     }
     ~Scene() { ptrt_destroy(ctx); }
     Scene(const Scene &) = delete;
@@ -226,7 +246,10 @@ class Scene {
     void setBlueNoiseTable(const float *table) { needBackend(); check(ptrt_set_blue_noise(ctx, table), "blue noise upload failed"); }
 
     // ---- accumulation / acceleration settings (scene.cuh:1270-1296) -----------------
-    void resetAccumulation() { frame_count_ = 0; }
+    void resetAccumulation() {
+        frame_count_ = 0;
+        prev_view_proj = camera.get_view_proj(); // scene.cuh:1282: no motion across a reset
+    }
     void setBVHLeafTarget(int target, int tol = 5) {
         bvhLeafTarget_ = target < 1 ? 1 : target;
         bvhLeafTol_ = tol < 0 ? 0 : tol;
@@ -537,6 +560,10 @@ class Scene {
     vec3 *getNormalBuffer() { return (vec3 *)ptrt_device_buffer(ctx, PTRT_BUF_NORMAL); }
     float *getDepthBuffer() { return (float *)ptrt_device_buffer(ctx, PTRT_BUF_DEPTH); }
     int *getObjectIdBuffer() { return (int *)ptrt_device_buffer(ctx, PTRT_BUF_OBJECT_ID); }
+    float *getMotionVectorBuffer() { return (float *)ptrt_device_buffer(ctx, PTRT_BUF_MOTION); } // float2 per pixel
+    vec3 *getDenoisedBuffer() { return (vec3 *)ptrt_device_buffer(ctx, PTRT_BUF_DENOISED); }
+    mat4 getPrevViewProjMatrix() const { return prev_view_proj; }
+    mat4 getViewProjMatrix() const { return camera.get_view_proj(); }
 
     // ---- access for tests, tools and the tile farm -----------------------------------
     ptrt_ctx *backend() { return ctx; }
@@ -563,7 +590,8 @@ class Scene {
 
     ptrt_ctx *ctx = nullptr;
     bool geometryDirty = true, materialsDirty = true, lightsDirty = true, cameraDirty = true, skyDirty = true;
-    bool warnedPost = false;
+    bool warnedPost = false, denoiserAllocated = false;
+    mat4 prev_view_proj; // proj*view of the previous frame (scene.cuh:113)
 
     // flattened arrays handed to the back end
     std::vector<ptrt_mesh_desc> flatMeshes;
@@ -753,11 +781,20 @@ class Scene {
             std::cerr << "ERROR: Mesh descriptors not allocated!\n";
             return;
         }
-        if ((perfSettings.enableDenoiser || perfSettings.enableBloom || perfSettings.resolutionScale != 1.0f) &&
+        const bool denoise = perfSettings.enableDenoiser && denoiserAllocated;
+        if ((perfSettings.enableBloom || perfSettings.resolutionScale != 1.0f ||
+             (perfSettings.enableDenoiser && !denoiserAllocated)) &&
             !warnedPost) {
-            std::cerr << "NOTE: denoiser/bloom/resolution scaling are not part of this back end; "
-                         "rendering the raw path-traced frame\n";
+            std::cerr << "NOTE: bloom and resolution scaling are not part of this back end"
+                      << (perfSettings.enableDenoiser && !denoiserAllocated ? ", and a band (tile) context cannot denoise" : "")
+                      << "; those stages are skipped\n";
             warnedPost = true;
+        }
+        if (denoiserAllocated) { // scene.cuh:1103-1127: motion vectors + Denoiser::denoise after the trace
+            check(ptrt_set_option(ctx, "denoiser_active", denoise ? 1 : 0), "denoiser option");
+            check(ptrt_set_option(ctx, "motion_vectors", (denoise && perfSettings.enableMotionVectors) ? 1 : 0),
+                  "denoiser option");
+            check(ptrt_set_prev_view_proj(ctx, prev_view_proj.m), "prev view-proj");
         }
         updateAccelerationStructures();
         if (cameraDirty) {
@@ -776,5 +813,6 @@ class Scene {
         if (rc != PTRT_OK) // launch errors are logged, not thrown (scene.cuh:1036-1042)
             std::cerr << "HIP kernel launch failed at path_trace_kernel: " << ptrt_last_error(ctx) << "\n";
         frame_count_++;
+        prev_view_proj = camera.get_view_proj(); // scene.cuh:1208
     }
 };

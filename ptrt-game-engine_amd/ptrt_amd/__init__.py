@@ -26,7 +26,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 PTRT_OK = 0
-BUF_ACCUM, BUF_NORMAL, BUF_DEPTH, BUF_OBJECT_ID, BUF_RGB8, BUF_RNG = range(6)
+BUF_ACCUM, BUF_NORMAL, BUF_DEPTH, BUF_OBJECT_ID, BUF_RGB8, BUF_RNG, BUF_DENOISED, BUF_MOTION = range(8)
 DEFAULT_SEED = 12345
 HOST_ONLY = -1
 
@@ -177,6 +177,11 @@ _sig("hs_get_settings", None, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POI
 _sig("hs_set_mesh_material", C.c_int, _vp, C.c_int, _fp)
 _sig("hs_upload", C.c_int, _vp)
 _sig("hs_commit_object_changes", C.c_int, _vp)
+_sig("hs_get_view_proj", None, _vp, C.c_int, _fp)
+_sig("ptrt_denoiser_default_settings", None, _vp)
+_sig("ptrt_denoiser_enable", C.c_int, _vp, _vp)
+_sig("ptrt_denoiser_disable", C.c_int, _vp)
+_sig("ptrt_set_prev_view_proj", C.c_int, _vp, _fp)
 _sig("hs_refit_object_changes", C.c_int, _vp)
 _sig("hs_refit_from_device", C.c_int, _vp, C.c_int, _vp)
 _sig("ptrt_update_vertices", C.c_int, _vp, C.c_int, _fp, C.c_int, C.c_int)
@@ -346,6 +351,12 @@ class Scene:
     def uploadToGPU(self): self._chk(lib.hs_upload(self._h))
     def commitObjectChanges(self): self._chk(lib.hs_commit_object_changes(self._h))
 
+    def view_proj(self, current=False):
+        """proj*view (16 floats, column-major as mat4 stores them): previous frame's by default."""
+        m = np.zeros(16, dtype=np.float32)
+        lib.hs_get_view_proj(self._h, 1 if current else 0, _fptr(m))
+        return m
+
     def refitObjectChanges(self):
         """Dynamic vertices, same topology: host + GPU BVH refit instead of the reference's rebuild."""
         self._chk(lib.hs_refit_object_changes(self._h))
@@ -371,7 +382,8 @@ class Scene:
         n = self.tile_rows * self.width
         shape, dt = {BUF_ACCUM: ((n, 3), np.float32), BUF_NORMAL: ((n, 3), np.float32), BUF_DEPTH: ((n,), np.float32),
                      BUF_OBJECT_ID: ((n,), np.int32), BUF_RGB8: ((self.tile_rows, self.width, 3), np.uint8),
-                     BUF_RNG: ((n, 6), np.uint32)}[kind]
+                     BUF_RNG: ((n, 6), np.uint32), BUF_DENOISED: ((n, 3), np.float32),
+                     BUF_MOTION: ((n, 2), np.float32)}[kind]
         out = np.empty(shape, dtype=dt)
         self._cchk(lib.ptrt_read_buffer(self.ctx, kind, out.ctypes.data_as(_vp), out.nbytes))
         return out

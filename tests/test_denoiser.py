@@ -1,0 +1,132 @@
+"""Motion vectors + spatiotemporal denoiser: oracle properties on CPU, GPU parity
+(bit-exact) on the box.  PARITY UNPINNED w.r.t. the CUDA reference (no vectors exist for this stage)."""
+import numpy as np
+import pytest
+
+
+def cornell(P, w, h, **kw):
+    s = P.Scene(w, h, **kw)
+    P.scenes.cornell(s)
+    return s
+
+
+def oracle_frames(P, O, s, blue_noise, frames, spp, depth, camera_moves=None):
+    """Path trace + motion vectors + denoise on the CPU, frame by frame, mirroring render_to_device."""
+    W, H = s.width, s.height
+    rng = O.xorwow_init(P.DEFAULT_SEED, 0, W * H)
+    dn = O.Denoiser(W, H)
+    out = []
+    for f in range(frames):
+        if camera_moves and f in camera_moves:
+            s.moveCamera(camera_moves[f])
+            fc = 0
+        else:
+            fc = s.getFrameCount() if s.device >= 0 else f
+        pvp = s.view_proj(current=False)
+        d = s.flatten()
+        r = O.render(d, W, H, spp, depth, fc if s.device < 0 else s.getFrameCount(), blue_noise, rng, threads=8)
+        mv = O.motion_vectors(r["depth"], W, H, d.contents.camera, pvp)
+        den = dn.denoise(r["accum"], r["normal"], r["depth"], mv, r["object_id"])
+        out.append(dict(noisy=r["accum"], motion=mv, denoised=den, rgb8=O.tonemap(den, W, H), depth=r["depth"]))
+        yield out[-1]
+
+
+def test_oracle_denoiser_properties(P, O, blue_noise):
+    W, H = 64, 48
+    s = cornell(P, W, H, device=P.HOST_ONLY)
+    d = s.flatten()
+    rng = O.xorwow_init(P.DEFAULT_SEED, 0, W * H)
+    dn = O.Denoiser(W, H)
+    pvp = s.view_proj()
+    errs, hist = [], []
+    ref = O.render(d, W, H, 256, 4, 0, blue_noise, O.xorwow_init(777, 0, W * H), threads=8)["accum"]
+    for f in range(6):
+        r = O.render(d, W, H, 1, 4, f, blue_noise, rng, threads=8)
+        mv = O.motion_vectors(r["depth"], W, H, d.contents.camera, pvp)
+        assert np.abs(mv).max() < 1e-6            # static camera: no motion (prev view-proj == current)
+        den = dn.denoise(r["accum"], r["normal"], r["depth"], mv, r["object_id"])
+        assert np.isfinite(den).all() and den.min() >= 0.0
+        errs.append((np.mean((r["accum"] - ref) ** 2), np.mean((den - ref) ** 2)))
+        hist.append(dn.hlen.copy())
+    assert all(dm < 0.6 * nm for nm, dm in errs[1:])          # denoised is closer to the converged image
+    assert errs[-1][1] < 1.5 * errs[0][1] and errs[-1][1] < 0.2 * errs[-1][0]   # stays there as history accumulates
+    # the first frame seeds the history with length 1 and immediately accumulates onto it (denoiser.cuh:899-910)
+    assert hist[0].max() == 2.0 and hist[-1].max() == 7.0 and hist[-1].min() >= 1.0
+    # a constant image is a fixed point of the whole chain
+    n = W * H
+    flat = np.full((n, 3), 0.25, np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (n, 1))
+    dep = np.full(n, 5.0, np.float32)
+    dn2 = O.Denoiser(W, H)
+    for _ in range(3):
+        o = dn2.denoise(flat, nrm, dep, np.zeros((n, 2), np.float32), np.zeros(n, np.int32))
+        assert np.allclose(o, flat, rtol=0, atol=1e-6)   # (weights are renormalised in fp32)
+    # sky pixels (depth > 1e9) pass through untouched
+    dep[:100] = 1e30
+    noisy = np.random.RandomState(0).uniform(0, 1, (n, 3)).astype(np.float32)
+    o = O.Denoiser(W, H).denoise(noisy, nrm, dep, np.zeros((n, 2), np.float32), np.zeros(n, np.int32))
+    assert np.array_equal(o[:100], noisy[:100])
+
+
+def test_motion_vectors_follow_the_camera(P, O, blue_noise):
+    W, H = 64, 48
+    s = cornell(P, W, H, device=P.HOST_ONLY)
+    d = s.flatten()
+    r = O.render(d, W, H, 1, 1, 0, blue_noise, O.xorwow_init(1, 0, W * H))
+    prev = s.view_proj(current=True)
+    s.moveCamera((0.4, 0.0, 5.0))              # camera moves right -> the scene moves left on screen
+    d = s.flatten()
+    r2 = O.render(d, W, H, 1, 1, 0, blue_noise, O.xorwow_init(1, 0, W * H))
+    # Scene::moveCamera resets accumulation, which also resets prev_view_proj (scene.cuh:1282) ...
+    assert np.array_equal(s.view_proj(), s.view_proj(current=True))
+    # ... so feed the true previous matrix to see the motion
+    mv = O.motion_vectors(r2["depth"], W, H, d.contents.camera, prev).reshape(H, W, 2)
+    # Camera::set_position keeps the look-at point at the old focus distance (1 unit, camera.cuh:271-299),
+    # so moving 0.4 to the right pivots the view ~22 degrees to the left: the scene slides right (+u)
+    assert 0.2 < mv[..., 0].mean() < 0.6 and abs(mv[..., 1].mean()) < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,spp", [((96, 64), 1), ((131, 77), 2)])
+def test_gpu_denoiser_bit_exact(P, O, blue_noise, size, spp):
+    W, H = size
+    s = cornell(P, W, H)
+    s.setSamplesPerPixel(spp)
+    s.setMaxBounceDepth(4)
+    s.setDenoiserEnabled(True)
+    s.setBloomEnabled(False)
+    s.initBlueNoise()
+    s.uploadToGPU()
+    rng = O.xorwow_init(P.DEFAULT_SEED, 0, W * H)
+    dn = O.Denoiser(W, H)
+    for f in range(5):
+        if f == 3:
+            s.moveCamera((0.3, 0.2, 5.0))     # resets accumulation (frame 0 jitter) but keeps the denoiser history
+        fc = s.getFrameCount()
+        pvp = s.view_proj()
+        rgb = s.render_to_host()
+        d = s.flatten()
+        r = O.render(d, W, H, spp, 4, fc, blue_noise, rng, threads=8)
+        assert np.array_equal(s.read(P.BUF_ACCUM).view(np.uint32), r["accum"].view(np.uint32)), f
+        mv = O.motion_vectors(r["depth"], W, H, d.contents.camera, pvp)
+        assert np.array_equal(s.read(P.BUF_MOTION).view(np.uint32), mv.view(np.uint32)), f"motion, frame {f}"
+        den = dn.denoise(r["accum"], r["normal"], r["depth"], mv, r["object_id"])
+        g = s.read(P.BUF_DENOISED)
+        bad = np.flatnonzero((g.view(np.uint32) != den.view(np.uint32)).any(axis=1))
+        assert bad.size == 0, f"frame {f}: denoised differs in {bad.size} px, first {bad[:5]}: {g[bad[0]]} vs {den[bad[0]]}"
+        assert np.array_equal(rgb, O.tonemap(den, W, H)), f
+    # disabling the denoiser returns the raw frame; history survives for when it is re-enabled
+    s.setDenoiserEnabled(False)
+    fc = s.getFrameCount()
+    rgb = s.render_to_host()
+    r = O.render(s.flatten(), W, H, spp, 4, fc, blue_noise, rng, threads=8)
+    assert np.array_equal(rgb, O.tonemap(r["accum"], W, H))
+    s.close()
+
+
+@pytest.mark.gpu
+def test_band_contexts_cannot_denoise(P):
+    s = P.Scene(64, 64, tile_y0=16, tile_rows=16)
+    assert P.lib.ptrt_denoiser_enable(s.ctx, None) == -1
+    assert b"full-frame" in P.lib.ptrt_last_error(s.ctx)
+    s.close()

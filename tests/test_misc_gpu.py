@@ -41,6 +41,8 @@ def test_gpu_reproduces_committed_goldens(P, name):
     P.scenes.cornell(s) if scene == "cornell" else P.scenes.showcase(s, segments=12)
     s.setSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
+    s.setDenoiserEnabled(False)
+    s.setBloomEnabled(False)
     s.initBlueNoise()
     s.uploadToGPU()
     s.setFrameCount(frame)
@@ -88,6 +90,8 @@ def test_full_size_properties(P):
     P.scenes.cornell(s)
     s.setSamplesPerPixel(4)
     s.setMaxBounceDepth(4)
+    s.setDenoiserEnabled(False)
+    s.setBloomEnabled(False)
     s.initBlueNoise()
     s.uploadToGPU()
     s.set_option("count_rays", 1)

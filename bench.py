@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--denoise", action="store_true",
+                    help="also run motion vectors + the spatiotemporal denoiser each frame (N=1 only; not the headline)")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +100,8 @@ def main():
     scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, local_rank)
     scene.setSamplesPerPixel(args.spp)
     scene.setMaxBounceDepth(args.depth)
+    if args.denoise and world == 1:
+        scene.setDenoiserEnabled(True)
     scene.initBlueNoise()
     scene.uploadToGPU()
     scene.set_option("count_rays", 1)

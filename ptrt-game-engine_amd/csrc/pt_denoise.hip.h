@@ -1,4 +1,4 @@
-// pt_denoise.hip.h -- motion vectors + spatiotemporal denoiser + stand-alone tonemap (gfx950).
+// pt_denoise.hip.h -- motion vectors + spatiotemporal denoiser + tonemap (gfx950).
 // the stage that follows the path tracer in every real preset.
 //
 // Reference (file:line of Mark-Rindler/PTRT-game-engine):
@@ -10,15 +10,21 @@
 //   Denoiser::denoiseChannel      rendering/denoiser.cuh:884-964 (non-split path)
 //   tonemap_kernel                scene/scene.cuh:2004-2047
 //
-// These are HBM-bound image passes.  What is done differently from the reference's launch list:
-//   * no device-to-device copies: the six cudaMemcpy per channel per frame (history <- result,
-//     denoiser.cuh:922-930,1049-1061) become pointer swaps of double-buffered history sets;
-//   * init_moments + the first-frame history copy are folded into the temporal kernel's
-//     first-frame branch; the a-trous chain reads the accumulated mean in place and ping-pongs
-//     two scratch images;
-//   * 64x4-pixel workgroups so a wave touches one contiguous row segment.
-// The reference runs temporal_accumulation in place (out_mean == current_color, a data race);
-// here every read sees the pre-kernel image (see oracle/denoiser_oracle.cpp).
+// These are image passes whose first cut (one dword load per component, as the reference's
+// vec3/float arrays suggest) was bound by vector-memory INSTRUCTION issue, not bandwidth: an
+// a-trous tap cost 9 dword loads, 225 per pixel, and a pass ran at 7 % of the HBM roofline.
+// Layout here (all internal; the API-visible vec3/float buffers are untouched):
+//     G4  = {normal.xyz, depth}      one global_load_dwordx4 per tap, double-buffered so the
+//                                    previous frame's G-buffer needs no copy
+//     C4  = {rgb, variance}          a-trous ping-pong images
+//     H1  = {mean.rgb, history len}, H2 = {m2.rgb, -}   history, double-buffered (swap, no copies)
+// so a tap is 2 x dwordx4 + 1 dword.  The reference's six cudaMemcpy per channel per frame
+// (denoiser.cuh:922-930,1049-1061) become pointer swaps; init_moments + the first-frame history
+// copy are a branch of the temporal kernel; the last a-trous pass writes the API's vec3 image and
+// the tonemapped RGB8 in the same store phase.  Arithmetic per pixel is the reference's, term by
+// term (same contract as the path: dot() fused, __expf -> det_exp), so results are bit-identical
+// to oracle/denoiser_oracle.cpp.  The reference runs temporal_accumulation in place (a race);
+// here every read sees the pre-kernel image, as in the oracle.
 #pragma once
 #include "pt_device.hip.h"
 
@@ -39,6 +45,8 @@ PT_DEV void st3(float *p, size_t i, f3 v) {
     p[i * 3 + 1] = v.y;
     p[i * 3 + 2] = v.z;
 }
+PT_DEV f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+PT_DEV float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 PT_DEV f3 max3(f3 a, f3 b) { return mk3(max_(a.x, b.x), max_(a.y, b.y), max_(a.z, b.z)); }
 PT_DEV f3 min3(f3 a, f3 b) { return mk3(min_(a.x, b.x), min_(a.y, b.y), min_(a.z, b.z)); }
 PT_DEV float luminance(f3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
@@ -61,62 +69,60 @@ PT_DEV bool edge_disc(float d0, float d1, f3 n0, f3 n1, int o0, int o1, float dt
         return;                                                                                                \
     const int idx = y * W + x;
 
-// ------------------------------------------------------------------ motion vectors
-__global__ __launch_bounds__(256) void motion_vector_kernel(float *__restrict__ out_mv, const float *__restrict__ depth,
-                                                            int W, int H, f3 origin, f3 llc, f3 hor, f3 ver,
-                                                            const float *__restrict__ pvp) {
+// ------------------------------------------------------------------ prep: G4 pack + motion vectors + firefly
+// One pass over the path tracer's outputs: packs {normal, depth}, writes the motion vector
+// (when enabled) and the firefly-suppressed colour image {rgb, 0}.
+__global__ __launch_bounds__(256) void prep_kernel(float4 *__restrict__ g4, float *__restrict__ out_mv,
+                                                   float4 *__restrict__ cur4, const float *__restrict__ accum,
+                                                   const float *__restrict__ normal, const float *__restrict__ depth, int W,
+                                                   int H, f3 origin, f3 llc, f3 hor, f3 ver, const float *__restrict__ pvp,
+                                                   int do_motion, float sky, int firefly) {
     PT_PIXEL_XY
     const float d = depth[idx];
-    if (d >= 1e29f) {
-        out_mv[idx * 2] = 0.0f;
-        out_mv[idx * 2 + 1] = 0.0f;
-        return;
-    }
-    const float u = ((float)x + 0.5f) / (float)W;
-    const float v = ((float)y + 0.5f) / (float)H;
-    const float s = u, t = 1.0f - v;
-    const f3 rd = llc + hor * s + ver * t - origin;
-    const f3 dir = normalize(rd);
-    const f3 wp = origin + dir * d;
-    const float cx = pvp[0] * wp.x + pvp[4] * wp.y + pvp[8] * wp.z + pvp[12] * 1.0f;
-    const float cy = pvp[1] * wp.x + pvp[5] * wp.y + pvp[9] * wp.z + pvp[13] * 1.0f;
-    const float cw = pvp[3] * wp.x + pvp[7] * wp.y + pvp[11] * wp.z + pvp[15] * 1.0f;
-    const float ndc_x = cx / cw, ndc_y = cy / cw;
-    const float prev_u = (ndc_x + 1.0f) * 0.5f;
-    const float prev_v = (1.0f - ndc_y) * 0.5f;
-    out_mv[idx * 2] = u - prev_u;
-    out_mv[idx * 2 + 1] = v - prev_v;
-}
-
-// ------------------------------------------------------------------ firefly suppression
-__global__ __launch_bounds__(256) void firefly_kernel(float *__restrict__ out, const float *__restrict__ in,
-                                                      const float *__restrict__ depth, const float *__restrict__ normal,
-                                                      float sky, int W, int H, int enabled) {
-    PT_PIXEL_XY
-    const f3 center = ld3(in, idx);
-    if (!enabled || is_sky(depth[idx], ld3(normal, idx), sky)) {
-        st3(out, idx, center);
-        return;
-    }
-    f3 mx = mk3(0.0f);
-    bool any = false;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            if (dx == 0 && dy == 0)
-                continue;
-            const int nx = x + dx, ny = y + dy;
-            if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
-                mx = max3(mx, ld3(in, ny * W + nx));
-                any = true;
-            }
+    const f3 n = ld3(normal, idx);
+    g4[idx] = mk4(n, d);
+    if (do_motion) { // motion_vector_kernel
+        if (d >= 1e29f) {
+            out_mv[idx * 2] = 0.0f;
+            out_mv[idx * 2 + 1] = 0.0f;
+        } else {
+            const float u = ((float)x + 0.5f) / (float)W;
+            const float v = ((float)y + 0.5f) / (float)H;
+            const float s = u, t = 1.0f - v;
+            const f3 dir = normalize(llc + hor * s + ver * t - origin);
+            const f3 wp = origin + dir * d;
+            const float cx = pvp[0] * wp.x + pvp[4] * wp.y + pvp[8] * wp.z + pvp[12] * 1.0f;
+            const float cy = pvp[1] * wp.x + pvp[5] * wp.y + pvp[9] * wp.z + pvp[13] * 1.0f;
+            const float cw = pvp[3] * wp.x + pvp[7] * wp.y + pvp[11] * wp.z + pvp[15] * 1.0f;
+            const float ndc_x = cx / cw, ndc_y = cy / cw;
+            const float prev_u = (ndc_x + 1.0f) * 0.5f;
+            const float prev_v = (1.0f - ndc_y) * 0.5f;
+            out_mv[idx * 2] = u - prev_u;
+            out_mv[idx * 2 + 1] = v - prev_v;
         }
-    if (any) {
-        f3 c = min3(center, mx * 1.25f);
-        c = min3(c, mk3(10.0f));
-        st3(out, idx, c);
-    } else {
-        st3(out, idx, center);
     }
+    // firefly_suppression_kernel
+    const f3 center = ld3(accum, idx);
+    f3 outc = center;
+    if (firefly && !is_sky(d, n, sky)) {
+        f3 mx = mk3(0.0f);
+        bool any = false;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dx == 0 && dy == 0)
+                    continue;
+                const int nx = x + dx, ny = y + dy;
+                if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
+                    mx = max3(mx, ld3(accum, ny * W + nx));
+                    any = true;
+                }
+            }
+        if (any) {
+            outc = min3(center, mx * 1.25f);
+            outc = min3(outc, mk3(10.0f));
+        }
+    }
+    cur4[idx] = mk4(outc, 0.0f);
 }
 
 // ------------------------------------------------------------------ temporal accumulation
@@ -127,46 +133,38 @@ struct Taps {
     float total_w;
     int nearest;
 };
-PT_DEV f3 sample3(const float *buf, const Taps &t) {
-    if (t.total_w < 1e-6f) {
-        for (int k = 0; k < 4; ++k)
-            if (t.valid[k])
-                return ld3(buf, t.idx[k]);
-        return ld3(buf, t.nearest);
-    }
-    return (ld3(buf, t.idx[0]) * t.w[0] + ld3(buf, t.idx[1]) * t.w[1] + ld3(buf, t.idx[2]) * t.w[2] +
-            ld3(buf, t.idx[3]) * t.w[3]) *
-           (1.0f / t.total_w);
+PT_DEV int first_valid(const Taps &t) {
+    int pick = t.nearest;
+    for (int k = 3; k >= 0; --k)
+        if (t.valid[k])
+            pick = t.idx[k];
+    return pick;
 }
-PT_DEV float sample1(const float *buf, const Taps &t) {
-    if (t.total_w < 1e-6f) {
-        for (int k = 0; k < 4; ++k)
-            if (t.valid[k])
-                return buf[t.idx[k]];
-        return buf[t.nearest];
-    }
-    return (buf[t.idx[0]] * t.w[0] + buf[t.idx[1]] * t.w[1] + buf[t.idx[2]] * t.w[2] + buf[t.idx[3]] * t.w[3]) *
-           (1.0f / t.total_w);
+PT_DEV f3 blend3(f3 a, f3 b, f3 c, f3 d, const Taps &t) {
+    return (a * t.w[0] + b * t.w[1] + c * t.w[2] + d * t.w[3]) * (1.0f / t.total_w);
+}
+PT_DEV float blend1(float a, float b, float c, float d, const Taps &t) {
+    return (a * t.w[0] + b * t.w[1] + c * t.w[2] + d * t.w[3]) * (1.0f / t.total_w);
 }
 
-// cur: firefly-filtered image.  prev_* : last frame's history (on the first frame they are not
-// read: the history IS the current image, init_moments folded in).  out_*: the new history.
-__global__ __launch_bounds__(256) void temporal_kernel(
-    float *__restrict__ out_mean, float *__restrict__ out_m2, float *__restrict__ out_len, const float *__restrict__ cur,
-    const float *__restrict__ prev_mean, const float *__restrict__ prev_m2, const float *__restrict__ prev_len,
-    const float *__restrict__ motion, const float *__restrict__ depth, const float *__restrict__ prev_depth,
-    const float *__restrict__ normal, const float *__restrict__ prev_normal, const int *__restrict__ object_id,
-    const int *__restrict__ prev_object_id, DenoiseSettings S, int first_frame, int W, int H) {
+// cur4: firefly-filtered image.  ph1/ph2/pg4/pobj: last frame's history and G-buffer (on the first
+// frame the history IS the current frame: mean = cur, m2 = cur^2, len = 1, G = current).
+__global__ __launch_bounds__(256) void temporal_kernel(float4 *__restrict__ oh1, float4 *__restrict__ oh2,
+                                                       const float4 *__restrict__ cur4, const float4 *__restrict__ ph1,
+                                                       const float4 *__restrict__ ph2, const float *__restrict__ motion,
+                                                       const float4 *__restrict__ g4, const float4 *__restrict__ pg4,
+                                                       const int *__restrict__ object_id, const int *__restrict__ pobj,
+                                                       DenoiseSettings S, int first_frame, int W, int H) {
     PT_PIXEL_XY
     const bool use_obj = S.use_object_ids != 0;
-    const f3 cur_c = ld3(cur, idx);
-    const float d = depth[idx];
-    const f3 n = ld3(normal, idx);
+    const f3 cur_c = xyz(cur4[idx]);
+    const float4 g = g4[idx];
+    const float d = g.w;
+    const f3 n = xyz(g);
     const int obj_id = use_obj ? object_id[idx] : -1;
     if (is_sky(d, n, S.sky_depth_threshold)) {
-        st3(out_mean, idx, cur_c);
-        st3(out_m2, idx, cur_c * cur_c);
-        out_len[idx] = 1.0f;
+        oh1[idx] = mk4(cur_c, 1.0f);
+        oh2[idx] = mk4(cur_c * cur_c, 0.0f);
         return;
     }
     f3 nmean = mk3(0.0f), nm2 = mk3(0.0f);
@@ -174,10 +172,10 @@ __global__ __launch_bounds__(256) void temporal_kernel(
     for (int dy = -1; dy <= 1; ++dy)
         for (int dx = -1; dx <= 1; ++dx) {
             const int ni = clampi(y + dy, 0, H - 1) * W + clampi(x + dx, 0, W - 1);
-            const f3 nc = ld3(cur, ni);
+            const float4 ng = g4[ni];
             const int no = use_obj ? object_id[ni] : -1;
-            if (!edge_disc(d, depth[ni], n, ld3(normal, ni), obj_id, no, S.edge_depth_threshold, S.edge_normal_threshold,
-                           use_obj)) {
+            if (!edge_disc(d, ng.w, n, xyz(ng), obj_id, no, S.edge_depth_threshold, S.edge_normal_threshold, use_obj)) {
+                const f3 nc = xyz(cur4[ni]);
                 nmean = nmean + nc;
                 nm2 = nm2 + nc * nc;
                 ncount++;
@@ -202,11 +200,8 @@ __global__ __launch_bounds__(256) void temporal_kernel(
     f3 hist_mean = mk3(0.0f), hist_m2 = mk3(0.0f);
     float hist_len = 0.0f;
     if (valid) {
-        // on the first frame the history is this frame: mean = cur, m2 = cur^2, len = 1, G-buffers = current
-        const float *pm = first_frame ? cur : prev_mean;
-        const float *pd = first_frame ? depth : prev_depth;
-        const float *pn = first_frame ? normal : prev_normal;
-        const int *po = first_frame ? object_id : prev_object_id;
+        const float4 *hg = first_frame ? g4 : pg4;
+        const int *po = first_frame ? object_id : pobj;
         const float fx = prev_u - 0.5f, fy = prev_v - 0.5f;
         int x0 = (int)__builtin_floorf(fx), y0 = (int)__builtin_floorf(fy);
         int x1 = x0 + 1, y1 = y0 + 1;
@@ -221,41 +216,51 @@ __global__ __launch_bounds__(256) void temporal_kernel(
         t.idx[2] = y1 * W + x0;
         t.idx[3] = y1 * W + x1;
         const float bw[4] = {(1.0f - sx) * (1.0f - sy), sx * (1.0f - sy), (1.0f - sx) * sy, sx * sy};
+        float4 tg[4];
         for (int k = 0; k < 4; ++k) {
+            tg[k] = hg[t.idx[k]];
             const int o = use_obj ? po[t.idx[k]] : -1;
-            t.valid[k] = !edge_disc(d, pd[t.idx[k]], n, ld3(pn, t.idx[k]), obj_id, o, S.edge_depth_threshold,
-                                    S.edge_normal_threshold, use_obj);
+            t.valid[k] = !edge_disc(d, tg[k].w, n, xyz(tg[k]), obj_id, o, S.edge_depth_threshold, S.edge_normal_threshold,
+                                    use_obj);
             t.w[k] = t.valid[k] ? bw[k] : 0.0f;
         }
         t.total_w = t.w[0] + t.w[1] + t.w[2] + t.w[3];
         t.nearest = clampi((int)__builtin_floorf(prev_v), 0, H - 1) * W + clampi((int)__builtin_floorf(prev_u), 0, W - 1);
-        hist_mean = sample3(pm, t);
-        if (first_frame) {
-            // m2 history = cur*cur per texel, len history = 1: sample those images through the same taps
-            if (t.total_w < 1e-6f) {
-                int pick = t.nearest;
-                for (int k = 3; k >= 0; --k)
-                    if (t.valid[k])
-                        pick = t.idx[k];
-                const f3 c = ld3(cur, pick);
+        float hist_d;
+        if (t.total_w < 1e-6f) { // no usable tap: first valid one, else the nearest texel (denoiser.cuh:294-306)
+            const int pick = first_valid(t);
+            if (first_frame) {
+                const f3 c = xyz(cur4[pick]);
+                hist_mean = c;
                 hist_m2 = c * c;
                 hist_len = 1.0f;
             } else {
-                const f3 c0 = ld3(cur, t.idx[0]), c1 = ld3(cur, t.idx[1]), c2 = ld3(cur, t.idx[2]), c3 = ld3(cur, t.idx[3]);
-                hist_m2 = ((c0 * c0) * t.w[0] + (c1 * c1) * t.w[1] + (c2 * c2) * t.w[2] + (c3 * c3) * t.w[3]) * (1.0f / t.total_w);
-                hist_len = (1.0f * t.w[0] + 1.0f * t.w[1] + 1.0f * t.w[2] + 1.0f * t.w[3]) * (1.0f / t.total_w);
+                const float4 a = ph1[pick];
+                hist_mean = xyz(a);
+                hist_len = a.w;
+                hist_m2 = xyz(ph2[pick]);
             }
+            hist_d = hg[pick].w;
         } else {
-            hist_m2 = sample3(prev_m2, t);
-            hist_len = sample1(prev_len, t);
+            if (first_frame) {
+                const f3 c0 = xyz(cur4[t.idx[0]]), c1 = xyz(cur4[t.idx[1]]), c2 = xyz(cur4[t.idx[2]]), c3 = xyz(cur4[t.idx[3]]);
+                hist_mean = blend3(c0, c1, c2, c3, t);
+                hist_m2 = blend3(c0 * c0, c1 * c1, c2 * c2, c3 * c3, t);
+                hist_len = blend1(1.0f, 1.0f, 1.0f, 1.0f, t);
+            } else {
+                const float4 a0 = ph1[t.idx[0]], a1 = ph1[t.idx[1]], a2 = ph1[t.idx[2]], a3 = ph1[t.idx[3]];
+                hist_mean = blend3(xyz(a0), xyz(a1), xyz(a2), xyz(a3), t);
+                hist_len = blend1(a0.w, a1.w, a2.w, a3.w, t);
+                hist_m2 = blend3(xyz(ph2[t.idx[0]]), xyz(ph2[t.idx[1]]), xyz(ph2[t.idx[2]]), xyz(ph2[t.idx[3]]), t);
+            }
+            hist_d = blend1(tg[0].w, tg[1].w, tg[2].w, tg[3].w, t);
         }
-        const float hist_d = sample1(pd, t);
         if (use_obj && po[t.nearest] != obj_id)
             valid = false;
         const float dad = __builtin_fabsf(d - hist_d);
         if (dad > S.depth_reject_absolute || dad > S.depth_reject_relative * max_(1e-6f, d))
             valid = false;
-        if (dot(n, ld3(pn, t.nearest)) < S.normal_reject_threshold)
+        if (dot(n, xyz(hg[t.nearest])) < S.normal_reject_threshold)
             valid = false;
     }
     if (valid)
@@ -269,29 +274,30 @@ __global__ __launch_bounds__(256) void temporal_kernel(
         alpha = clampf(max_(variance_alpha, history_alpha), S.min_alpha, 1.0f);
         nlen = min_(hist_len + 1.0f, S.max_history);
     }
-    st3(out_mean, idx, hist_mean * (1.0f - alpha) + cur_c * alpha);
-    st3(out_m2, idx, hist_m2 * (1.0f - alpha) + (cur_c * cur_c) * alpha);
-    out_len[idx] = nlen;
+    oh1[idx] = mk4(hist_mean * (1.0f - alpha) + cur_c * alpha, nlen);
+    oh2[idx] = mk4(hist_m2 * (1.0f - alpha) + (cur_c * cur_c) * alpha, 0.0f);
 }
 
-// ------------------------------------------------------------------ variance estimate
-__global__ __launch_bounds__(256) void variance_kernel(float *__restrict__ out_var, const float *__restrict__ color,
-                                                       const float *__restrict__ m2, const float *__restrict__ hlen,
-                                                       const float *__restrict__ depth, const float *__restrict__ normal,
-                                                       const int *__restrict__ object_id, float sky, int use_obj_i, int W,
-                                                       int H) {
+// ------------------------------------------------------------------ variance estimate -> C4 = {mean, variance}
+__global__ __launch_bounds__(256) void variance_kernel(float4 *__restrict__ out_c4, const float4 *__restrict__ h1,
+                                                       const float4 *__restrict__ h2, const float4 *__restrict__ g4,
+                                                       const int *__restrict__ object_id, int *__restrict__ hist_obj,
+                                                       float sky, int use_obj_i, int W, int H) {
     PT_PIXEL_XY
     const bool uo = use_obj_i != 0;
-    const float d = depth[idx];
-    const f3 n = ld3(normal, idx);
-    const int obj = uo ? object_id[idx] : -1;
-    if (is_sky(d, n, sky)) {
-        out_var[idx] = 0.0f;
+    const float4 g = g4[idx];
+    const float4 a = h1[idx];
+    const f3 c = xyz(a);
+    const int cur_obj = object_id[idx];
+    hist_obj[idx] = cur_obj; // next frame's history object ids (the temporal pass of this frame is done)
+    const int obj = uo ? cur_obj : -1;
+    if (is_sky(g.w, xyz(g), sky)) {
+        out_c4[idx] = mk4(c, 0.0f);
         return;
     }
-    const f3 c = ld3(color, idx), cm2 = ld3(m2, idx);
+    const f3 cm2 = xyz(h2[idx]);
     const f3 var = max3(cm2 - (c * c), mk3(0.0f));
-    const float reliability = min_(hlen[idx] * 0.25f, 1.0f);
+    const float reliability = min_(a.w * 0.25f, 1.0f);
     const float boost = 1.0f + (1.0f - reliability) * 3.0f;
     f3 smean = mk3(0.0f), sm2 = mk3(0.0f);
     int count = 0;
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(256) void variance_kernel(float *__restrict__ out_v
             const int ni = clampi(y + dy, 0, H - 1) * W + clampi(x + dx, 0, W - 1);
             if (uo && object_id[ni] != obj)
                 continue;
-            const f3 nc = ld3(color, ni);
+            const f3 nc = xyz(h1[ni]);
             smean = smean + nc;
             sm2 = sm2 + nc * nc;
             count++;
@@ -310,83 +316,95 @@ __global__ __launch_bounds__(256) void variance_kernel(float *__restrict__ out_v
     sm2 = sm2 * inv;
     const f3 svar = max3(sm2 - smean * smean, mk3(0.0f));
     const f3 cv = max3(var * boost, svar);
-    out_var[idx] = 0.2126f * cv.x + 0.7152f * cv.y + 0.0722f * cv.z;
+    out_c4[idx] = mk4(c, 0.2126f * cv.x + 0.7152f * cv.y + 0.0722f * cv.z);
 }
 
-// ------------------------------------------------------------------ a-trous wavelet pass
-__global__ __launch_bounds__(256) void atrous_kernel(float *__restrict__ out, float *__restrict__ out_var,
-                                                     const float *__restrict__ in, const float *__restrict__ in_var,
-                                                     const float *__restrict__ normal, const float *__restrict__ depth,
-                                                     const int *__restrict__ object_id, int step, float sigma_lum,
-                                                     float sky, float edt, float ent, int use_obj_i, int W, int H) {
+// ------------------------------------------------------------------ a-trous wavelet pass on C4
+// LAST: also writes the API's vec3 image and the tonemapped RGB8 (rows flipped), saving two passes.
+template <bool LAST>
+__global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4, const float4 *__restrict__ in_c4,
+                                                     const float4 *__restrict__ g4, const int *__restrict__ object_id,
+                                                     int step, float sigma_lum, float sky, float edt, float ent, int use_obj_i,
+                                                     int W, int H, float *__restrict__ out3, unsigned char *__restrict__ rgb8) {
     PT_PIXEL_XY
     constexpr float KW[5] = {1.0f, 4.0f, 6.0f, 4.0f, 1.0f};
     const bool uo = use_obj_i != 0;
-    const f3 cc = ld3(in, idx), cn = ld3(normal, idx);
-    const float cd = depth[idx];
+    const float4 c4 = in_c4[idx];
+    const float4 g = g4[idx];
+    const f3 cc = xyz(c4), cn = xyz(g);
+    const float cd = g.w, cvar = c4.w;
     const int cobj = uo ? object_id[idx] : -1;
-    const float cvar = in_var[idx];
     const float clum = luminance(cc);
-    if (is_sky(cd, cn, sky)) {
-        st3(out, idx, cc);
-        out_var[idx] = cvar;
-        return;
-    }
-    const float var_scale = __builtin_sqrtf(max_(cvar, 1e-6f));
-    const float asl = sigma_lum * (1.0f + var_scale * 2.0f);
-    const float inv_sl2 = 1.0f / (2.0f * asl * asl + 1e-6f);
-    f3 sum = mk3(0.0f);
-    float sum_var = 0.0f, total_w = 0.0f;
-    for (int dy = -2; dy <= 2; ++dy)
-        for (int dx = -2; dx <= 2; ++dx) {
-            const int nx = x + dx * step, ny = y + dy * step;
-            if (nx < 0 || nx >= W || ny < 0 || ny >= H)
-                continue;
-            const int ni = ny * W + nx;
-            if (uo) {
-                const int nobj = object_id[ni];
-                if (cobj != nobj && cobj >= 0 && nobj >= 0)
+    f3 res = cc;
+    float res_var = cvar;
+    if (!is_sky(cd, cn, sky)) {
+        const float var_scale = __builtin_sqrtf(max_(cvar, 1e-6f));
+        const float asl = sigma_lum * (1.0f + var_scale * 2.0f);
+        const float inv_sl2 = 1.0f / (2.0f * asl * asl + 1e-6f);
+        f3 sum = mk3(0.0f);
+        float sum_var = 0.0f, total_w = 0.0f;
+        for (int dy = -2; dy <= 2; ++dy)
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int nx = x + dx * step, ny = y + dy * step;
+                if (nx < 0 || nx >= W || ny < 0 || ny >= H)
                     continue;
+                const int ni = ny * W + nx;
+                if (uo) {
+                    const int nobj = object_id[ni];
+                    if (cobj != nobj && cobj >= 0 && nobj >= 0)
+                        continue;
+                }
+                const float4 ng = g4[ni];
+                const float max_d = max_(cd, ng.w);
+                const float dd = __builtin_fabsf(cd - ng.w);
+                if (max_d > 1e-6f && dd / max_d > edt)
+                    continue;
+                const f3 nn = xyz(ng);
+                if (dot(cn, nn) < ent)
+                    continue;
+                if (is_sky(ng.w, nn, sky))
+                    continue;
+                const float4 nc4 = in_c4[ni];
+                const f3 nc = xyz(nc4);
+                const float ld = __builtin_fabsf(clum - luminance(nc));
+                const float wl = det_exp(-ld * ld * inv_sl2);
+                // atrous_kernel[k] = (a*b)/256 with a,b in {1,4,6}: products and the /256 are exact in fp32
+                const float weight = (KW[dy + 2] * KW[dx + 2] / 256.0f) * wl;
+                sum = sum + nc * weight;
+                sum_var += nc4.w * weight;
+                total_w += weight;
             }
-            const float nd = depth[ni];
-            const float max_d = max_(cd, nd);
-            const float dd = __builtin_fabsf(cd - nd);
-            if (max_d > 1e-6f && dd / max_d > edt)
-                continue;
-            const f3 nn = ld3(normal, ni);
-            if (dot(cn, nn) < ent)
-                continue;
-            if (is_sky(nd, nn, sky))
-                continue;
-            const f3 nc = ld3(in, ni);
-            const float ld = __builtin_fabsf(clum - luminance(nc));
-            const float wl = det_exp(-ld * ld * inv_sl2);
-            // atrous_kernel[k] = (a*b)/256 with a,b in {1,4,6}: products and the /256 are exact in fp32
-            const float weight = (KW[dy + 2] * KW[dx + 2] / 256.0f) * wl;
-            sum = sum + nc * weight;
-            sum_var += in_var[ni] * weight;
-            total_w += weight;
+        if (!(total_w < 1e-6f)) {
+            const float inv_w = 1.0f / total_w;
+            res = sum * inv_w;
+            res_var = sum_var * inv_w;
         }
-    if (total_w < 1e-6f) {
-        st3(out, idx, cc);
-        out_var[idx] = cvar;
+    }
+    if (LAST) {
+        st3(out3, idx, res);
+        unsigned char r, gg, b;
+        tonemap_pixel(res, r, gg, b);
+        const size_t o = ((size_t)(H - 1 - y) * W + x) * 3;
+        rgb8[o] = r;
+        rgb8[o + 1] = gg;
+        rgb8[o + 2] = b;
     } else {
-        const float inv_w = 1.0f / total_w;
-        st3(out, idx, sum * inv_w);
-        out_var[idx] = sum_var * inv_w;
+        out_c4[idx] = mk4(res, res_var);
     }
 }
 
-// ------------------------------------------------------------------ tonemap_kernel (scene.cuh:2004-2047)
-__global__ __launch_bounds__(256) void tonemap_kernel(unsigned char *__restrict__ out, const float *__restrict__ in, int W,
-                                                      int H) {
+// ------------------------------------------------------------------ stand-alone passes for atrous_iterations == 0
+__global__ __launch_bounds__(256) void c4_to_output_kernel(const float4 *__restrict__ in_c4, int W, int H,
+                                                           float *__restrict__ out3, unsigned char *__restrict__ rgb8) {
     PT_PIXEL_XY
+    const f3 res = xyz(in_c4[idx]);
+    st3(out3, idx, res);
     unsigned char r, g, b;
-    tonemap_pixel(ld3(in, idx), r, g, b);
+    tonemap_pixel(res, r, g, b);
     const size_t o = ((size_t)(H - 1 - y) * W + x) * 3;
-    out[o] = r;
-    out[o + 1] = g;
-    out[o + 2] = b;
+    rgb8[o] = r;
+    rgb8[o + 1] = g;
+    rgb8[o + 2] = b;
 }
 
 } // namespace pt

@@ -83,9 +83,10 @@ struct ptrt_ctx {
     // denoiser (class Denoiser, denoiser.cuh:781-1070): scratch + double-buffered history
     bool dn_on = false, dn_first = true;
     pt::DenoiseSettings dn{};
-    float *dn_ping = nullptr, *dn_pong = nullptr, *dn_var[2] = {nullptr, nullptr};
-    float *dn_hmean[2] = {nullptr, nullptr}, *dn_hm2[2] = {nullptr, nullptr}, *dn_hlen[2] = {nullptr, nullptr};
-    float *dn_hnormal = nullptr, *dn_hdepth = nullptr;
+    // float4 images (pt_denoise.hip.h): cur4 {rgb,0}; c4 {rgb,variance} ping-pong; g4 {normal,depth},
+    // h1 {mean,len}, h2 {m2,-} double-buffered across frames
+    float4 *dn_cur4 = nullptr, *dn_c4[2] = {nullptr, nullptr}, *dn_g4[2] = {nullptr, nullptr};
+    float4 *dn_h1[2] = {nullptr, nullptr}, *dn_h2[2] = {nullptr, nullptr};
     int *dn_hobj = nullptr;
     float *dn_motion = nullptr, *dn_out = nullptr, *dn_pvp = nullptr;
     int dn_cur = 0; // which history set holds the latest result
@@ -392,16 +393,13 @@ bool ctx_live(ptrt_ctx *c) {
 }
 
 void free_denoiser(ptrt_ctx *c) {
-    dfree(c->dn_ping);
-    dfree(c->dn_pong);
+    dfree(c->dn_cur4);
     for (int k = 0; k < 2; ++k) {
-        dfree(c->dn_var[k]);
-        dfree(c->dn_hmean[k]);
-        dfree(c->dn_hm2[k]);
-        dfree(c->dn_hlen[k]);
+        dfree(c->dn_c4[k]);
+        dfree(c->dn_g4[k]);
+        dfree(c->dn_h1[k]);
+        dfree(c->dn_h2[k]);
     }
-    dfree(c->dn_hnormal);
-    dfree(c->dn_hdepth);
     dfree(c->dn_hobj);
     dfree(c->dn_motion);
     dfree(c->dn_out);
@@ -411,48 +409,43 @@ void free_denoiser(ptrt_ctx *c) {
 
 // motion vectors -> Denoiser::denoise (non-split) -> tonemap of the denoised image, all on the
 // context's stream (Scene::render_to_device, scene.cuh:1103-1127,1204).  History hand-over is a
-// swap of the double-buffered sets; only the G-buffer history is copied (20 B/px).
+// swap of the double-buffered sets (history moments AND the packed G-buffer); no device copies.
+// 3 + atrous_iterations launches per frame: prep, temporal, variance, a-trous x N (the last one
+// also writes the API's vec3 image and the RGB8 frame).
 int run_denoiser(ptrt_ctx *c, unsigned char *rgb8) {
     const int W = c->W, H = c->H;
     const dim3 grid((W + 63) / 64, (H + 3) / 4), block(256);
-    const size_t n = c->npix;
     const pt::DenoiseSettings &S = c->dn;
-    if (c->mv_active) { // perfSettings.enableMotionVectors (scene.cuh:1103); otherwise the last vectors are reused
-        HIP_TRY(c, hipMemcpyAsync(c->dn_pvp, c->prev_view_proj, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(pt::motion_vector_kernel, grid, block, 0, c->stream, c->dn_motion, c->d_depth, W, H,
-                           c->cam.origin, c->cam.llc, c->cam.horizontal, c->cam.vertical, c->dn_pvp);
-    }
-    hipLaunchKernelGGL(pt::firefly_kernel, grid, block, 0, c->stream, c->dn_ping, c->d_accum, c->d_depth, c->d_normal,
-                       S.sky_depth_threshold, W, H, S.enable_firefly_suppression);
     const int prev = c->dn_cur, next = c->dn_cur ^ 1;
-    hipLaunchKernelGGL(pt::temporal_kernel, grid, block, 0, c->stream, c->dn_hmean[next], c->dn_hm2[next], c->dn_hlen[next],
-                       c->dn_ping, c->dn_hmean[prev], c->dn_hm2[prev], c->dn_hlen[prev], c->dn_motion, c->d_depth,
-                       c->dn_hdepth, c->d_normal, c->dn_hnormal, c->d_object_id, c->dn_hobj, S, c->dn_first ? 1 : 0, W, H);
+    // perfSettings.enableMotionVectors (scene.cuh:1103); when off the last vectors are reused
+    if (c->mv_active)
+        HIP_TRY(c, hipMemcpyAsync(c->dn_pvp, c->prev_view_proj, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pt::prep_kernel, grid, block, 0, c->stream, c->dn_g4[next], c->dn_motion, c->dn_cur4, c->d_accum,
+                       c->d_normal, c->d_depth, W, H, c->cam.origin, c->cam.llc, c->cam.horizontal, c->cam.vertical,
+                       c->dn_pvp, c->mv_active, S.sky_depth_threshold, S.enable_firefly_suppression);
+    hipLaunchKernelGGL(pt::temporal_kernel, grid, block, 0, c->stream, c->dn_h1[next], c->dn_h2[next], c->dn_cur4,
+                       c->dn_h1[prev], c->dn_h2[prev], c->dn_motion, c->dn_g4[next], c->dn_g4[prev], c->d_object_id,
+                       c->dn_hobj, S, c->dn_first ? 1 : 0, W, H);
     c->dn_cur = next;
-    hipLaunchKernelGGL(pt::variance_kernel, grid, block, 0, c->stream, c->dn_var[0], c->dn_hmean[next], c->dn_hm2[next],
-                       c->dn_hlen[next], c->d_depth, c->d_normal, c->d_object_id, S.sky_depth_threshold, S.use_object_ids, W, H);
+    hipLaunchKernelGGL(pt::variance_kernel, grid, block, 0, c->stream, c->dn_c4[0], c->dn_h1[next], c->dn_h2[next],
+                       c->dn_g4[next], c->d_object_id, c->dn_hobj, S.sky_depth_threshold, S.use_object_ids, W, H);
     const int steps[5] = {1, 2, 4, 8, 16};
     const int iters = S.atrous_iterations < 5 ? (S.atrous_iterations < 0 ? 0 : S.atrous_iterations) : 5;
-    const float *in = c->dn_hmean[next];
-    const float *vin = c->dn_var[0];
     for (int i = 0; i < iters; ++i) {
-        // a-trous reads the accumulated mean in place on its first pass, then ping-pongs two scratch images;
-        // the last pass writes the denoised output directly
-        float *out = (i == iters - 1) ? c->dn_out : ((i & 1) ? c->dn_pong : c->dn_ping);
-        float *vout = c->dn_var[(i + 1) & 1];
-        hipLaunchKernelGGL(pt::atrous_kernel, grid, block, 0, c->stream, out, vout, in, vin, c->d_normal, c->d_depth,
-                           c->d_object_id, steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
-                           S.edge_normal_threshold, S.use_object_ids, W, H);
-        in = out;
-        vin = vout;
+        const float4 *in = c->dn_c4[i & 1];
+        float4 *out = c->dn_c4[(i + 1) & 1];
+        if (i == iters - 1)
+            hipLaunchKernelGGL(pt::atrous_kernel<true>, grid, block, 0, c->stream, out, in, c->dn_g4[next], c->d_object_id,
+                               steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
+                               S.edge_normal_threshold, S.use_object_ids, W, H, c->dn_out, rgb8);
+        else
+            hipLaunchKernelGGL(pt::atrous_kernel<false>, grid, block, 0, c->stream, out, in, c->dn_g4[next], c->d_object_id,
+                               steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
+                               S.edge_normal_threshold, S.use_object_ids, W, H, (float *)nullptr, (unsigned char *)nullptr);
     }
     if (iters == 0)
-        HIP_TRY(c, hipMemcpyAsync(c->dn_out, in, n * 12, hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(pt::tonemap_kernel, grid, block, 0, c->stream, rgb8, c->dn_out, W, H);
+        hipLaunchKernelGGL(pt::c4_to_output_kernel, grid, block, 0, c->stream, c->dn_c4[0], W, H, c->dn_out, rgb8);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->dn_hnormal, c->d_normal, n * 12, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->dn_hdepth, c->d_depth, n * 4, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->dn_hobj, c->d_object_id, n * 4, hipMemcpyDeviceToDevice, c->stream));
     c->dn_first = false;
     return PTRT_OK;
 }
@@ -963,16 +956,13 @@ int ptrt_denoiser_enable(ptrt_ctx *c, const ptrt_denoiser_settings *s) {
     free_denoiser(c);
     std::memcpy(&c->dn, &d, sizeof d);
     const size_t n = c->npix;
-    HIP_TRY(c, hipMalloc((void **)&c->dn_ping, n * 12));
-    HIP_TRY(c, hipMalloc((void **)&c->dn_pong, n * 12));
+    HIP_TRY(c, hipMalloc((void **)&c->dn_cur4, n * 16));
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(c, hipMalloc((void **)&c->dn_var[k], n * 4));
-        HIP_TRY(c, hipMalloc((void **)&c->dn_hmean[k], n * 12));
-        HIP_TRY(c, hipMalloc((void **)&c->dn_hm2[k], n * 12));
-        HIP_TRY(c, hipMalloc((void **)&c->dn_hlen[k], n * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->dn_c4[k], n * 16));
+        HIP_TRY(c, hipMalloc((void **)&c->dn_g4[k], n * 16));
+        HIP_TRY(c, hipMalloc((void **)&c->dn_h1[k], n * 16));
+        HIP_TRY(c, hipMalloc((void **)&c->dn_h2[k], n * 16));
     }
-    HIP_TRY(c, hipMalloc((void **)&c->dn_hnormal, n * 12));
-    HIP_TRY(c, hipMalloc((void **)&c->dn_hdepth, n * 4));
     HIP_TRY(c, hipMalloc((void **)&c->dn_hobj, n * 4));
     HIP_TRY(c, hipMalloc((void **)&c->dn_motion, n * 8));
     HIP_TRY(c, hipMalloc((void **)&c->dn_out, n * 12));

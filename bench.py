@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--denoise", action="store_true",
                     help="also run motion vectors + the spatiotemporal denoiser each frame (N=1 only; not the headline)")
+    ap.add_argument("--rebuild", action="store_true",
+                    help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +131,8 @@ def main():
 
     def step():
         if water is not None:
-            scene.refitFromDevice(scene.water_mesh, water[counter[0] % len(water)].data_ptr())
+            move = scene.rebuildFromDevice if args.rebuild else scene.refitFromDevice
+            move(scene.water_mesh, water[counter[0] % len(water)].data_ptr())
             counter[0] += 1
         b = counter[1] & 1
         counter[1] += 1

@@ -226,6 +226,28 @@ int ptrt_set_sky(ptrt_ctx *ctx, const ptrt_vec3 *top, const ptrt_vec3 *bottom, i
 int ptrt_update_vertices(ptrt_ctx *ctx, int mesh_index, const float *verts, int vert_count, int verts_on_device);
 int ptrt_refit(ptrt_ctx *ctx);
 
+/* GPU BVH (re)build of one mesh -- what Scene::updateAccelerationStructures does on the CPU for
+ * every dirty mesh (scene.cuh:656-733: Mesh::buildBVH mesh.cuh:403-492 + upload/uploadBVH
+ * mesh.cuh:330-346,494-516), for a mesh whose FACE COUNT is unchanged.
+ * The reference builder's tree shape depends only on the face count (n > leafTarget+tol splits
+ * into n/2 and n-n/2), so the uploaded topology is kept and the faces are re-assigned to the
+ * leaf positions in Morton order of their current centroids (30-bit codes, stable radix sort on
+ * the GPU), followed by ptrt_refit().  All on the context's stream, nothing returns to the host.
+ * Depth and leaf sizes are the uploaded tree's, so the 24-entry stack bound keeps holding.
+ * Needs: every face of the mesh in exactly one leaf position (any tree Mesh::buildBVH makes),
+ * single-leaf TLAS.  ptrt_read_prim_order returns the resulting `primIndices` (mesh.cuh:57) so a
+ * host copy of the tree (and the oracle) can follow. */
+int ptrt_build_bvh(ptrt_ctx *ctx, int mesh_index);
+int ptrt_read_prim_order(ptrt_ctx *ctx, int mesh_index, int32_t *prim_indices_out, int count);
+
+/* The `Triangles` path of updatePTScene with a CHANGING triangle count (PTRTtransfer.cuh:2204-2385:
+ * a new triangle list every frame, e.g. a fluid surface).  For a triangle-soup mesh (face i =
+ * vertices 3i,3i+1,3i+2, what Scene::addTriangles makes) uploaded with room for N triangles:
+ * copies tri_count <= N triangles (9 floats each; a DEVICE pointer if on_device != 0) and turns the
+ * remaining N - tri_count into degenerate copies of the last real vertex -- never hit
+ * (|det| < EPSILON, intersection.cuh:229), never enlarging a box.  Follow with ptrt_build_bvh(). */
+int ptrt_update_triangles(ptrt_ctx *ctx, int mesh_index, const float *verts9, int tri_count, int on_device);
+
 /* ---- post-process "next" row: motion vectors + spatiotemporal denoiser ----
  * DenoiserSettings of the non-split path (src/pathtracer/rendering/denoiser.cuh:36-73); the
  * defaults are the reference's diffuse_* values. */

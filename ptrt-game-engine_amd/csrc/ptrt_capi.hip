@@ -7,6 +7,7 @@
 // scene, launch on the context's stream, time kernels with HIP events.
 // There is no CPU rendering path in this library.
 #include "../../include/ptrt.h"
+#include "pt_build.hip.h"
 #include "pt_denoise.hip.h"
 #include "pt_refit.hip.h"
 #include "pt_render.hip.h"
@@ -71,6 +72,15 @@ struct ptrt_ctx {
     std::vector<int> level_offset;  // level_offset[d] .. level_offset[d+1]: nodes at depth d+1
     std::vector<int> mesh_vert_base, mesh_vert_count;
     int n_slots = 0, n_leaves = 0;
+    // GPU rebuild support (ptrt_build_bvh, pt_build.hip.h)
+    int4 *d_face_src = nullptr;   // per face, mesh-major, original order: global vertex indices + face index
+    int *d_slot_pos = nullptr;    // per leaf slot: its position in the mesh's prim order
+    std::vector<int> mesh_face_base, mesh_face_count, mesh_slot_base, mesh_slot_count;
+    std::vector<unsigned char> mesh_rebuildable, mesh_is_soup;
+    uint32_t *d_sort_keys[2] = {nullptr, nullptr}, *d_sort_vals[2] = {nullptr, nullptr}, *d_sort_hist = nullptr,
+             *d_cbounds = nullptr;
+    float *d_centroids = nullptr;
+    int sort_capacity = 0;
     bool tlas_single_leaf = false, all_single_leaf = false, mats_full = false;
     int stack_entries = 1;
     int pair_meshes = 0, pair_tri_slots = 0, pair_max_leaf = 0;
@@ -288,6 +298,16 @@ void free_scene(ptrt_ctx *c) {
     dfree(c->d_leaf_dst);
     dfree(c->d_node_dst);
     dfree(c->d_level_nodes);
+    dfree(c->d_face_src);
+    dfree(c->d_slot_pos);
+    for (int k = 0; k < 2; ++k) {
+        dfree(c->d_sort_keys[k]);
+        dfree(c->d_sort_vals[k]);
+    }
+    dfree(c->d_sort_hist);
+    dfree(c->d_cbounds);
+    dfree(c->d_centroids);
+    c->sort_capacity = 0;
 }
 
 // flags bit1 (skipped by shadow rays) comes from the materials; re-applied on either upload.
@@ -627,6 +647,10 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     std::vector<float> all_verts;
     std::vector<int4> slot_face;
     std::vector<int> leaf_dst, node_dst, node_depth, vert_base(mesh_count), vert_count(mesh_count);
+    // rebuild bookkeeping
+    std::vector<int4> face_src;
+    std::vector<int> slot_pos, face_base(mesh_count), face_count(mesh_count), slot_base(mesh_count), slot_count(mesh_count);
+    std::vector<unsigned char> rebuildable(mesh_count, 0), is_soup(mesh_count, 0);
     for (int m = 0; m < mesh_count; ++m) {
         const ptrt_mesh_desc &M = meshes[m];
         if (!M.verts || !M.faces || !M.nodes || !M.prim_indices || M.node_count <= 0 || M.face_count <= 0 ||
@@ -642,6 +666,16 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
         vert_count[m] = M.vert_count;
         all_verts.insert(all_verts.end(), &M.verts[0].x, &M.verts[0].x + (size_t)M.vert_count * 3);
         const int vb = vert_base[m];
+        face_base[m] = (int)face_src.size();
+        face_count[m] = M.face_count;
+        slot_base[m] = (int)slot_face.size();
+        bool soup = M.vert_count == 3 * M.face_count;
+        for (int f = 0; f < M.face_count; ++f) {
+            const ptrt_tri &t = M.faces[f];
+            face_src.push_back(make_int4(vb + t.v0, vb + t.v1, vb + t.v2, f));
+            soup = soup && t.v0 == 3 * f && t.v1 == 3 * f + 1 && t.v2 == 3 * f + 2;
+        }
+        is_soup[m] = soup ? 1 : 0;
         bool bad = false;
         auto emit_leaf = [&](int start, int count, int dst) -> int {
             const int id = (int)R.leaves.size();
@@ -653,6 +687,7 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
             leaf_dst.push_back(dst);
             for (int i = 0; i < count; ++i) {
                 const int fidx = M.prim_indices[start + i];
+                slot_pos.push_back(start + i);
                 if (fidx < 0 || fidx >= M.face_count) {
                     bad = true;
                     R.tris.insert(R.tris.end(), 3, f4(0, 0, 0, 0));
@@ -682,6 +717,17 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
             R.max_depth = depth;
         if (root >= 0)
             all_leaf = false;
+        // a GPU rebuild permutes faces over prim positions: every position 0..face_count-1 must be a leaf slot once
+        slot_count[m] = (int)slot_face.size() - slot_base[m];
+        if (slot_count[m] == M.face_count && M.prim_count == M.face_count) {
+            std::vector<unsigned char> used((size_t)M.face_count, 0);
+            bool once = true;
+            for (int s = slot_base[m]; s < slot_base[m] + slot_count[m]; ++s) {
+                once = once && !used[(size_t)slot_pos[s]];
+                used[(size_t)slot_pos[s]] = 1;
+            }
+            rebuildable[m] = once ? 1 : 0;
+        }
         float4 *rec = &recs[(size_t)m * pt::MESH_REC_F4];
         const ptrt_bvh_node &rn = M.nodes[0];
         rec[0] = f4(rn.bmin.x, rn.bmin.y, rn.bmin.z, as_f(root));
@@ -758,6 +804,16 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
             return rc;
         if (int rc = upload(c, c->d_level_nodes, level_nodes))
             return rc;
+        if (int rc = upload(c, c->d_face_src, face_src))
+            return rc;
+        if (int rc = upload(c, c->d_slot_pos, slot_pos))
+            return rc;
+        c->mesh_face_base = face_base;
+        c->mesh_face_count = face_count;
+        c->mesh_slot_base = slot_base;
+        c->mesh_slot_count = slot_count;
+        c->mesh_rebuildable = rebuildable;
+        c->mesh_is_soup = is_soup;
         c->mesh_vert_base = vert_base;
         c->mesh_vert_count = vert_count;
         c->n_slots = (int)slot_face.size();
@@ -914,6 +970,113 @@ int ptrt_refit(ptrt_ctx *c) {
     hipLaunchKernelGGL(pt::refit_tlas_root_kernel, dim3(1), dim3(64), 0, c->stream, c->d_mesh_recs, c->d_tlas_leaves,
                        c->d_tlas_mesh_ids, c->tlas_root_ref, c->d_tlas_root_box);
     HIP_TRY(c, hipGetLastError());
+    return PTRT_OK;
+}
+
+int ptrt_build_bvh(ptrt_ctx *c, int mesh) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: bad context");
+    if (!c->have_geometry)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_build_bvh: geometry not uploaded");
+    if (mesh < 0 || mesh >= c->n_meshes)
+        return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: no mesh %d", mesh);
+    if (!c->mesh_rebuildable[mesh])
+        return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: mesh %d's uploaded BVH does not place every face in exactly one "
+                                       "leaf position; rebuild on the host and re-upload", mesh);
+    if (!c->tlas_single_leaf)
+        return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: needs a single-leaf TLAS; rebuild and re-upload instead");
+    if (int rc = set_device(c))
+        return rc;
+    const int n = c->mesh_face_count[mesh];
+    const int n_waves = (n + pt::RS_WAVE_KEYS - 1) / pt::RS_WAVE_KEYS;
+    if (n > c->sort_capacity) {
+        for (int k = 0; k < 2; ++k) {
+            dfree(c->d_sort_keys[k]);
+            dfree(c->d_sort_vals[k]);
+        }
+        dfree(c->d_sort_hist);
+        dfree(c->d_centroids);
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_sort_keys[k], (size_t)n * 4));
+            HIP_TRY(c, hipMalloc((void **)&c->d_sort_vals[k], (size_t)n * 4));
+        }
+        HIP_TRY(c, hipMalloc((void **)&c->d_sort_hist, (size_t)n_waves * 256 * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->d_centroids, (size_t)n * 12));
+        if (!c->d_cbounds)
+            HIP_TRY(c, hipMalloc((void **)&c->d_cbounds, 6 * 4));
+        c->sort_capacity = n;
+    }
+    const int B = 256, G = (n + B - 1) / B;
+    const int4 *faces = c->d_face_src + c->mesh_face_base[mesh];
+    HIP_TRY(c, hipMemsetAsync(c->d_cbounds, 0xff, 12, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_cbounds + 3, 0, 12, c->stream));
+    hipLaunchKernelGGL(pt::centroid_bounds_kernel, dim3(G), dim3(B), 0, c->stream, c->d_verts, faces, n, c->d_centroids,
+                       c->d_cbounds);
+    hipLaunchKernelGGL(pt::morton_kernel, dim3(G), dim3(B), 0, c->stream, c->d_centroids, c->d_cbounds, n, c->d_sort_keys[0],
+                       c->d_sort_vals[0]);
+    const int wg = (n_waves + pt::RS_BLOCK / 64 - 1) / (pt::RS_BLOCK / 64);
+    int cur = 0;
+    for (int shift = 0; shift < 32; shift += 8) { // the top pass only sees bits 24..29 of the 30-bit code
+        hipLaunchKernelGGL(pt::rs_hist_kernel, dim3(wg), dim3(pt::RS_BLOCK), 0, c->stream, c->d_sort_keys[cur], n, shift,
+                           c->d_sort_hist, n_waves);
+        hipLaunchKernelGGL(pt::rs_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_sort_hist, n_waves * 256);
+        hipLaunchKernelGGL(pt::rs_scatter_kernel, dim3(wg), dim3(pt::RS_BLOCK), 0, c->stream, c->d_sort_keys[cur],
+                           c->d_sort_vals[cur], n, shift, c->d_sort_hist, n_waves, c->d_sort_keys[cur ^ 1],
+                           c->d_sort_vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(pt::apply_order_kernel, dim3(G), dim3(B), 0, c->stream, c->d_sort_vals[cur], c->d_slot_pos, faces,
+                       c->d_slot_face, c->mesh_slot_base[mesh], n);
+    HIP_TRY(c, hipGetLastError());
+    return ptrt_refit(c);
+}
+
+int ptrt_update_triangles(ptrt_ctx *c, int mesh, const float *verts9, int tri_count, int on_device) {
+    if (!ctx_live(c) || (!verts9 && tri_count > 0) || tri_count < 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_update_triangles: bad argument");
+    if (!c->have_geometry)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_update_triangles: geometry not uploaded");
+    if (mesh < 0 || mesh >= c->n_meshes)
+        return fail(c, PTRT_E_INVALID, "ptrt_update_triangles: no mesh %d", mesh);
+    if (!c->mesh_is_soup[mesh])
+        return fail(c, PTRT_E_INVALID, "ptrt_update_triangles: mesh %d is not a triangle soup (face i = vertices 3i..3i+2)", mesh);
+    if (tri_count > c->mesh_face_count[mesh])
+        return fail(c, PTRT_E_INVALID, "ptrt_update_triangles: mesh %d was uploaded with room for %d triangles, got %d", mesh,
+                    c->mesh_face_count[mesh], tri_count);
+    if (int rc = set_device(c))
+        return rc;
+    float *dst = c->d_verts + (size_t)c->mesh_vert_base[mesh] * 3;
+    if (tri_count > 0)
+        HIP_TRY(c, hipMemcpyAsync(dst, verts9, (size_t)tri_count * 36, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                  c->stream));
+    const int total = c->mesh_vert_count[mesh], real = tri_count * 3;
+    if (total > real)
+        hipLaunchKernelGGL(pt::pad_soup_kernel, dim3((total - real + 255) / 256), dim3(256), 0, c->stream, dst, real, total);
+    HIP_TRY(c, hipGetLastError());
+    if (!on_device)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTRT_OK;
+}
+
+int ptrt_read_prim_order(ptrt_ctx *c, int mesh, int32_t *out, int count) {
+    if (!ctx_live(c) || !out)
+        return fail(c, PTRT_E_INVALID, "ptrt_read_prim_order: bad argument");
+    if (!c->have_geometry)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_read_prim_order: geometry not uploaded");
+    if (mesh < 0 || mesh >= c->n_meshes || !c->mesh_rebuildable[mesh] || count != c->mesh_face_count[mesh])
+        return fail(c, PTRT_E_INVALID, "ptrt_read_prim_order: mesh %d has %d rebuildable prim positions, asked for %d", mesh,
+                    (mesh >= 0 && mesh < c->n_meshes && c->mesh_rebuildable[mesh]) ? c->mesh_face_count[mesh] : 0, count);
+    if (int rc = set_device(c))
+        return rc;
+    std::vector<int4> sf((size_t)count);
+    std::vector<int> pos((size_t)count);
+    HIP_TRY(c, hipMemcpyAsync(sf.data(), c->d_slot_face + c->mesh_slot_base[mesh], (size_t)count * 16, hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipMemcpyAsync(pos.data(), c->d_slot_pos + c->mesh_slot_base[mesh], (size_t)count * 4, hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < count; ++i)
+        out[pos[(size_t)i]] = sf[(size_t)i].w;
     return PTRT_OK;
 }
 

@@ -230,6 +230,25 @@ int hs_refit_from_device(void *s, int mesh, const void *device_xyz) {
     HS_TRY(static_cast<Scene *>(s)->refitFromDevice((size_t)mesh, static_cast<const float *>(device_xyz)));
     return 0;
 }
+int hs_rebuild_object_changes(void *s, int sync_host_copy) {
+    HS_TRY(static_cast<Scene *>(s)->rebuildObjectChanges(sync_host_copy != 0));
+    return 0;
+}
+int hs_rebuild_from_device(void *s, int mesh, const void *device_xyz) {
+    HS_TRY(static_cast<Scene *>(s)->rebuildFromDevice((size_t)mesh, static_cast<const float *>(device_xyz)));
+    return 0;
+}
+int hs_update_triangles(void *s, int mesh, const void *verts9, int tri_count, int on_device) {
+    HS_TRY(static_cast<Scene *>(s)->updateTriangles((size_t)mesh, static_cast<const float *>(verts9), tri_count, on_device != 0));
+    return 0;
+}
+int hs_mesh_prim_indices(void *s, int mesh, int *out, int count) {
+    const Mesh *m = static_cast<Scene *>(s)->getMesh((size_t)mesh);
+    if (!m || count != (int)m->bvhPrimIndices.size())
+        return -1;
+    std::memcpy(out, m->bvhPrimIndices.data(), (size_t)count * sizeof(int));
+    return 0;
+}
 int hs_render_to_device(void *s, void *device_pixels) {
     HS_TRY(static_cast<Scene *>(s)->render_to_device(static_cast<unsigned char *>(device_pixels)));
     return 0;

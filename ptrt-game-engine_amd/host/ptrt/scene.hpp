@@ -463,6 +463,74 @@ class Scene {
         resetAccumulation();
     }
 
+    // commitObjectChanges() for meshes whose face count is unchanged, with the BVH rebuilt ON THE GPU
+    // (ptrt_build_bvh: Morton-order median split over the uploaded tree shape + refit) instead of
+    // Mesh::buildBVH on the CPU + re-upload (scene.cuh:656-733).  The host copy of each rebuilt tree
+    // follows (prim order read back, boxes refitted) so flatten() describes what the GPU traverses.
+    void rebuildObjectChanges(bool syncHostCopy = true) {
+        needBackend();
+        if (!gpu_resources_initialized || geometryDirty)
+            throw std::runtime_error("rebuildObjectChanges: call uploadToGPU() first");
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            Mesh *m = meshes[i].get();
+            if (!m->vertsDirty)
+                continue;
+            m->vertsDirty = false;
+            check(ptrt_update_vertices(ctx, (int)i, &m->vertices[0].x, (int)m->vertices.size(), 0),
+                  "Failed to update vertices");
+            check(ptrt_build_bvh(ctx, (int)i), "Failed to build BVH");
+            if (syncHostCopy)
+                syncPrimOrder(i);
+        }
+        if (syncHostCopy) {
+            buildTLAS();
+            flat.tlas_nodes = h_tlasNodes.data();
+        }
+        resetAccumulation();
+    }
+    // same, new positions already in device memory (host copy not updated)
+    void rebuildFromDevice(size_t mesh, const float *device_xyz) {
+        needBackend();
+        Mesh *m = getMesh(mesh);
+        if (!m)
+            throw std::runtime_error("rebuildFromDevice: no such mesh");
+        check(ptrt_update_vertices(ctx, (int)mesh, device_xyz, (int)m->vertices.size(), 1), "Failed to update vertices");
+        check(ptrt_build_bvh(ctx, (int)mesh), "Failed to build BVH");
+        resetAccumulation();
+    }
+    // updatePTScene's `Triangles` path (PTRTtransfer.cuh:2204-2385) for a soup mesh made by
+    // addTriangles with room for its original triangle count: `tri_count` new triangles (9 floats
+    // each) from host or device memory, BVH rebuilt on the GPU.  The host copy of the mesh gets the
+    // same padded vertices when the data is on the host.
+    void updateTriangles(size_t mesh, const float *verts9, int tri_count, bool on_device = false) {
+        needBackend();
+        Mesh *m = getMesh(mesh);
+        if (!m)
+            throw std::runtime_error("updateTriangles: no such mesh");
+        check(ptrt_update_triangles(ctx, (int)mesh, verts9, tri_count, on_device ? 1 : 0), "Failed to update triangles");
+        check(ptrt_build_bvh(ctx, (int)mesh), "Failed to build BVH");
+        if (!on_device) {
+            const size_t real = (size_t)tri_count * 3;
+            for (size_t v = 0; v < m->vertices.size(); ++v) {
+                const size_t s = v < real ? v : (real ? real - 1 : 0);
+                m->vertices[v] = real ? vec3(verts9[s * 3], verts9[s * 3 + 1], verts9[s * 3 + 2]) : vec3(0.0f);
+            }
+            syncPrimOrder(mesh);
+            buildTLAS();
+            flat.tlas_nodes = h_tlasNodes.data();
+        }
+        resetAccumulation();
+    }
+    // host copy of mesh `i`'s tree := what the GPU now traverses
+    void syncPrimOrder(size_t i) {
+        Mesh *m = getMesh(i);
+        if (!m)
+            throw std::runtime_error("syncPrimOrder: no such mesh");
+        check(ptrt_read_prim_order(ctx, (int)i, m->bvhPrimIndices.data(), (int)m->bvhPrimIndices.size()),
+              "Failed to read the prim order");
+        m->refitBVH();
+    }
+
     bool hasObjectChanges() const {
         for (auto &m : meshes)
             if (m->bvhDirty)

@@ -186,6 +186,13 @@ _sig("hs_refit_object_changes", C.c_int, _vp)
 _sig("hs_refit_from_device", C.c_int, _vp, C.c_int, _vp)
 _sig("ptrt_update_vertices", C.c_int, _vp, C.c_int, _fp, C.c_int, C.c_int)
 _sig("ptrt_refit", C.c_int, _vp)
+_sig("ptrt_build_bvh", C.c_int, _vp, C.c_int)
+_sig("ptrt_read_prim_order", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.c_int)
+_sig("ptrt_update_triangles", C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int)
+_sig("hs_rebuild_object_changes", C.c_int, _vp, C.c_int)
+_sig("hs_rebuild_from_device", C.c_int, _vp, C.c_int, _vp)
+_sig("hs_update_triangles", C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int)
+_sig("hs_mesh_prim_indices", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.c_int)
 _sig("hs_render_to_device", C.c_int, _vp, _vp)
 _sig("hs_render_to_host", C.c_int, _vp, _vp)
 _sig("hs_get_frame_count", C.c_int, _vp)
@@ -364,6 +371,30 @@ class Scene:
     def refitFromDevice(self, mesh, device_ptr):
         """New vertex positions (n x 3 float32) already in device memory -> update + GPU refit, no host sync."""
         self._chk(lib.hs_refit_from_device(self._h, mesh, C.c_void_p(device_ptr)))
+
+    def rebuildObjectChanges(self, sync_host_copy=True):
+        """commitObjectChanges for unchanged face counts with the BVH rebuilt on the GPU (ptrt_build_bvh)."""
+        self._chk(lib.hs_rebuild_object_changes(self._h, int(sync_host_copy)))
+
+    def rebuildFromDevice(self, mesh, device_ptr):
+        """New vertex positions already in device memory -> update + GPU BVH rebuild, no host sync."""
+        self._chk(lib.hs_rebuild_from_device(self._h, mesh, C.c_void_p(device_ptr)))
+
+    def updateTriangles(self, mesh, verts9, tri_count=None, device_ptr=None):
+        """A new triangle list (<= the uploaded count) for a soup mesh + GPU rebuild: numpy (n,9) or a device pointer."""
+        if device_ptr is not None:
+            self._chk(lib.hs_update_triangles(self._h, mesh, C.c_void_p(device_ptr), int(tri_count), 1))
+            return
+        a = np.ascontiguousarray(verts9, dtype=np.float32).reshape(-1, 9)
+        self._chk(lib.hs_update_triangles(self._h, mesh, a.ctypes.data_as(_vp), a.shape[0], 0))
+
+    def primIndices(self, mesh):
+        """Host copy of the mesh's `primIndices` (mesh.cuh:57)."""
+        n = self.meshCounts(mesh)[1]
+        out = np.zeros(n, dtype=np.int32)
+        self._chk(lib.hs_mesh_prim_indices(self._h, mesh, out.ctypes.data_as(C.POINTER(C.c_int)), n))
+        return out
+
     def getFrameCount(self): return lib.hs_get_frame_count(self._h)
     def setFrameCount(self, f): lib.hs_set_frame_count(self._h, f)
 

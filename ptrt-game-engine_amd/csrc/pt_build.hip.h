@@ -44,15 +44,17 @@ __device__ __forceinline__ float from_ordered_bits(uint32_t u) {
 __global__ __launch_bounds__(256) void centroid_bounds_kernel(const float *__restrict__ verts,
                                                               const int4 *__restrict__ face_src, int n_faces,
                                                               float *__restrict__ centroids, uint32_t *cbounds) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float c[3] = {0.0f, 0.0f, 0.0f};
-    const bool ok = i < n_faces;
-    if (ok) {
+    // grid-stride: few workgroups, so the six global atomics per workgroup do not pile up
+    uint32_t tmn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, tmx[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_faces; i += gridDim.x * blockDim.x) {
         const int4 f = face_src[i];
         for (int k = 0; k < 3; ++k) {
             // (a + b + c) * (1/3), the reference's centroid (mesh.cuh:425)
-            c[k] = (verts[f.x * 3 + k] + verts[f.y * 3 + k] + verts[f.z * 3 + k]) * (1.0f / 3.0f);
-            centroids[(size_t)i * 3 + k] = c[k];
+            const float c = (verts[f.x * 3 + k] + verts[f.y * 3 + k] + verts[f.z * 3 + k]) * (1.0f / 3.0f);
+            centroids[(size_t)i * 3 + k] = c;
+            const uint32_t o = ordered_bits(c);
+            tmn[k] = o < tmn[k] ? o : tmn[k];
+            tmx[k] = o > tmx[k] ? o : tmx[k];
         }
     }
     __shared__ uint32_t lo[3], hi[3];
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void centroid_bounds_kernel(const float *__res
     }
     __syncthreads();
     for (int k = 0; k < 3; ++k) {
-        uint32_t mn = ok ? ordered_bits(c[k]) : 0xffffffffu, mx = ok ? ordered_bits(c[k]) : 0u;
+        uint32_t mn = tmn[k], mx = tmx[k];
         for (int off = 32; off > 0; off >>= 1) {
             const uint32_t a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
             mn = a < mn ? a : mn;
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(256) void morton_kernel(const float *__restrict__ c
 
 // ---- stable LSD radix sort, 8 bits per pass.  A wave owns RS_WAVE_KEYS consecutive keys; the
 // histogram is kept per wave so the scatter needs no inter-wave ordering inside a workgroup.
-// hist layout: [digit][wave] (digit-major), so one exclusive scan over the whole array yields
-// every wave's first output position for every digit.
+// hist layout: [wave][digit]; after rs_scan_kernel hist[w][d] is wave w's first output position
+// for digit d (keys of smaller digits first, then the same digit in earlier waves).
 __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const uint32_t *__restrict__ keys, int n, int shift,
                                                            uint32_t *__restrict__ hist, int n_waves) {
     __shared__ uint32_t h[RS_BLOCK / 64][256];
@@ -135,30 +137,46 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const uint32_t *__res
     __syncthreads();
     if (gw < n_waves)
         for (int d = lane; d < 256; d += 64)
-            hist[(size_t)d * n_waves + gw] = h[w][d];
+            hist[(size_t)gw * 256 + d] = h[w][d];
 }
 
-// exclusive scan of `count` entries in place, one workgroup of 1024
-__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t *__restrict__ data, int count) {
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (count + 1023) / 1024;
-    const int b = t * per, e = (b + per < count) ? b + per : count;
+// One workgroup: thread (seg, d) owns digit d over a quarter of the waves.  Column sums (loads
+// independent of each other, coalesced over d), a 256-wide exclusive scan of the digit totals
+// in LDS, then the columns are rewritten as running positions.
+// (counts in `hist`, positions out to `pos`: distinct buffers, so the loads do not wait on the stores)
+__global__ __launch_bounds__(1024) void rs_scan_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ pos,
+                                                       int n_waves) {
+    __shared__ uint32_t seg_total[4][256], digit_base[256], wave_sum[4];
+    const int d = threadIdx.x & 255, seg = threadIdx.x >> 8;
+    const int per = (n_waves + 3) / 4;
+    const int w0 = seg * per, w1 = (w0 + per < n_waves) ? w0 + per : n_waves;
     uint32_t s = 0;
-    for (int i = b; i < e; ++i)
-        s += data[i];
-    part[t] = s;
+    for (int w = w0; w < w1; ++w)
+        s += hist[(size_t)w * 256 + d];
+    seg_total[seg][d] = s;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the partial sums
-        const uint32_t v = (t >= off) ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (seg == 0) { // threads 0..255 = waves 0..3: exclusive scan of the 256 digit totals
+        const uint32_t tot = seg_total[0][d] + seg_total[1][d] + seg_total[2][d] + seg_total[3][d];
+        const int lane = d & 63;
+        uint32_t inc = tot;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off);
+            if (lane >= off)
+                inc += t;
+        }
+        if (lane == 63)
+            wave_sum[d >> 6] = inc;
+        digit_base[d] = inc - tot;
     }
-    uint32_t run = part[t] - s;
-    for (int i = b; i < e; ++i) {
-        const uint32_t v = data[i];
-        data[i] = run;
+    __syncthreads();
+    uint32_t run = digit_base[d];
+    for (int k = 0; k < (d >> 6); ++k)
+        run += wave_sum[k];
+    for (int k = 0; k < seg; ++k)
+        run += seg_total[k][d];
+    for (int w = w0; w < w1; ++w) {
+        const uint32_t v = hist[(size_t)w * 256 + d];
+        pos[(size_t)w * 256 + d] = run;
         run += v;
     }
 }
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const uint32_t *__
     if (gw >= n_waves)
         return; // no workgroup-level synchronisation below
     for (int d = lane; d < 256; d += 64)
-        next[w][d] = hist[(size_t)d * n_waves + gw];
+        next[w][d] = hist[(size_t)gw * 256 + d];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -209,8 +227,10 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const uint32_t *__
 // leaf slot s of the mesh holds prim position slot_pos[s]; give it the face ranked there
 __global__ __launch_bounds__(256) void apply_order_kernel(const uint32_t *__restrict__ order, const int *__restrict__ slot_pos,
                                                           const int4 *__restrict__ face_src, int4 *__restrict__ slot_face,
-                                                          int slot_base, int n_slots) {
+                                                          int slot_base, int n_slots, uint32_t *cbounds) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6)
+        cbounds[i] = i < 3 ? 0xffffffffu : 0u; // ready for the next build's atomics (saves two memset launches)
     if (i >= n_slots)
         return;
     const int s = slot_base + i;

@@ -7,12 +7,14 @@
 //   1. repack_tris_kernel    triangle packets {v0|face, e1, e2} from the new vertices
 //   2. refit_leaves_kernel   leaf boxes = min/max over the leaf's triangle vertices, stored into
 //                            the parent's child-pair slot (or the mesh root box)
-//   3. refit_level_kernel    one launch per tree level, deepest first: node box = union of its
-//                            two child boxes, stored into ITS parent's slot.  A kernel boundary
-//                            per level instead of in-kernel arrival counters: cross-XCD L2s are
-//                            not coherent, and a level is microseconds of work.
-//   4. refit_tlas_root_kernel  mesh world boxes (Transform3D::transformAABB, transform.cuh:399-416)
-//                            -> root box of the single-leaf TLAS
+//   3. refit_level_kernel    one launch per WIDE tree level (> 2048 nodes), deepest first: node
+//                            box = union of its two child boxes, stored into ITS parent's slot.
+//                            A kernel boundary per level instead of in-kernel arrival counters:
+//                            cross-XCD L2s are not coherent, and a level is microseconds of work.
+//   4. refit_top_levels_kernel  the narrow levels near the root in ONE workgroup (barrier between
+//                            levels; an empty launch costs ~4.6 us, a 13-level tree paid that 13x),
+//                            then the mesh world boxes (Transform3D::transformAABB,
+//                            transform.cuh:399-416) -> root box of the single-leaf TLAS
 // All boxes are exact min/max of fp32 values, so a host refit of the same topology gives the
 // same bits (Mesh::refitBVH in host/ptrt/mesh.hpp is what the oracle is fed).
 #pragma once
@@ -81,10 +83,9 @@ __global__ void refit_level_kernel(const int *__restrict__ level_nodes, int coun
     store_box(nodes, mesh_recs, node_dst[n], lo, hi);
 }
 
-__global__ void refit_tlas_root_kernel(const float4 *__restrict__ mesh_recs, const int2 *__restrict__ tlas_leaves,
-                                       const int *__restrict__ tlas_mesh_ids, int root_ref, float4 *root_box) {
-    if (blockIdx.x != 0 || threadIdx.x != 0)
-        return;
+// mesh world boxes (Transform3D::transformAABB, transform.cuh:399-416) -> root box of the single-leaf TLAS
+__device__ inline void tlas_root_box(const float4 *mesh_recs, const int2 *tlas_leaves, const int *tlas_mesh_ids, int root_ref,
+                                     float4 *root_box) {
     const int2 lf = tlas_leaves[~root_ref];
     float3 lo = make_float3(1e30f, 1e30f, 1e30f), hi = make_float3(-1e30f, -1e30f, -1e30f);
     for (int i = 0; i < lf.y; ++i) {
@@ -102,6 +103,33 @@ __global__ void refit_tlas_root_kernel(const float4 *__restrict__ mesh_recs, con
     }
     root_box[0] = make_float4(lo.x, lo.y, lo.z, 0.0f);
     root_box[1] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+}
+
+// The levels near the root hold few nodes each (2^(d-1)); one workgroup walks them all, deepest
+// first, with a workgroup barrier between levels: a workgroup lives on one CU and shares its L1,
+// so the barrier's workgroup-scope release/acquire makes a level's stores visible to the next.
+// Thread 0 then derives the TLAS root box from the mesh root boxes just written.
+struct TopLevels {
+    int begin[24], count[24];
+    int n;
+};
+__global__ __launch_bounds__(1024) void refit_top_levels_kernel(const int *__restrict__ level_nodes, TopLevels T,
+                                                                const int *__restrict__ node_dst, float4 *nodes,
+                                                                float4 *mesh_recs, const int2 *__restrict__ tlas_leaves,
+                                                                const int *__restrict__ tlas_mesh_ids, int root_ref,
+                                                                float4 *root_box) {
+    for (int l = 0; l < T.n; ++l) {
+        for (int i = threadIdx.x; i < T.count[l]; i += 1024) {
+            const int n = level_nodes[T.begin[l] + i];
+            const float4 a = nodes[(size_t)n * 4 + 0], b = nodes[(size_t)n * 4 + 1], c = nodes[(size_t)n * 4 + 2];
+            const float3 lo = make_float3(fminf(a.x, b.z), fminf(a.y, b.w), fminf(a.z, c.x));
+            const float3 hi = make_float3(fmaxf(a.w, c.y), fmaxf(b.x, c.z), fmaxf(b.y, c.w));
+            store_box(nodes, mesh_recs, node_dst[n], lo, hi);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        tlas_root_box(mesh_recs, tlas_leaves, tlas_mesh_ids, root_ref, root_box);
 }
 
 } // namespace pt

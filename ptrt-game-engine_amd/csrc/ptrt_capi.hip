@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
 #include <string>
@@ -81,6 +82,9 @@ struct ptrt_ctx {
              *d_cbounds = nullptr;
     float *d_centroids = nullptr;
     int sort_capacity = 0;
+    std::map<int, hipGraphExec_t> graphs; // refit (-1) / rebuild-of-mesh-m (m) launch sequences
+    hipStream_t capture_stream = nullptr;
+    int use_graphs = 0; // measured: replaying the sequence as a hipGraph gains nothing on ROCm 7.2
     bool tlas_single_leaf = false, all_single_leaf = false, mats_full = false;
     int stack_entries = 1;
     int pair_meshes = 0, pair_tri_slots = 0, pair_max_leaf = 0;
@@ -284,7 +288,10 @@ int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nod
     return root;
 }
 
+void drop_graphs(ptrt_ctx *c);
+
 void free_scene(ptrt_ctx *c) {
+    drop_graphs(c); // captured launch sequences hold arena pointers
     dfree(c->d_mesh_recs);
     dfree(c->d_nodes);
     dfree(c->d_tris);
@@ -410,6 +417,104 @@ int pair_mode(const ptrt_ctx *c, int geom) {
 bool ctx_live(ptrt_ctx *c) {
     std::lock_guard<std::mutex> lock(g_live_mutex);
     return c && g_live.count(c);
+}
+
+// ---- dynamic geometry: launch sequences, replayed as hipGraphs ------------------------------
+// A refit is ~16 and a rebuild ~35 microsecond-sized launches; issued one by one they cost more in
+// launch gaps than in work.  The sequences are fixed for a given upload (same kernels, grids and
+// arena pointers), so each is captured once on a private stream and replayed with one
+// hipGraphLaunch on the context's stream.  Key -1 = refit, key m >= 0 = rebuild of mesh m + refit.
+void drop_graphs(ptrt_ctx *c) {
+    for (auto &kv : c->graphs)
+        (void)hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+}
+
+int enqueue_refit(ptrt_ctx *c, hipStream_t st) {
+    const int B = 256;
+    if (c->n_slots > 0)
+        hipLaunchKernelGGL(pt::repack_tris_kernel, dim3((c->n_slots + B - 1) / B), dim3(B), 0, st, c->d_verts,
+                           c->d_slot_face, c->d_tris, c->n_slots);
+    if (c->n_leaves > 0)
+        hipLaunchKernelGGL(pt::refit_leaves_kernel, dim3((c->n_leaves + B - 1) / B), dim3(B), 0, st, c->d_verts,
+                           c->d_slot_face, c->d_leaves, c->d_leaf_dst, c->d_nodes, c->d_mesh_recs, c->n_leaves);
+    // wide levels: one launch each, deepest first; the narrow levels near the root (<= 2048 nodes) and the
+    // TLAS root box: one workgroup, barriers between levels (a tiny launch costs ~4.6 us whatever it does)
+    pt::TopLevels T{};
+    bool top = false;
+    for (int d = (int)c->level_offset.size() - 1; d >= 1; --d) { // depth d nodes: [offset[d-1], offset[d])
+        const int begin = c->level_offset[d - 1], count = c->level_offset[d] - begin;
+        if (count <= 0)
+            continue;
+        top = top || count <= 2048; // counts shrink towards the root; once narrow, the rest goes to the fused kernel
+        if (top) {
+            T.begin[T.n] = begin;
+            T.count[T.n] = count;
+            ++T.n;
+        } else {
+            hipLaunchKernelGGL(pt::refit_level_kernel, dim3((count + B - 1) / B), dim3(B), 0, st, c->d_level_nodes + begin,
+                               count, c->d_node_dst, c->d_nodes, c->d_mesh_recs);
+        }
+    }
+    hipLaunchKernelGGL(pt::refit_top_levels_kernel, dim3(1), dim3(1024), 0, st, c->d_level_nodes, T, c->d_node_dst,
+                       c->d_nodes, c->d_mesh_recs, c->d_tlas_leaves, c->d_tlas_mesh_ids, c->tlas_root_ref,
+                       c->d_tlas_root_box);
+    HIP_TRY(c, hipGetLastError());
+    return PTRT_OK;
+}
+
+int enqueue_build(ptrt_ctx *c, int mesh, hipStream_t st) {
+    const int n = c->mesh_face_count[mesh];
+    const int n_waves = (n + pt::RS_WAVE_KEYS - 1) / pt::RS_WAVE_KEYS;
+    const int B = 256, G = (n + B - 1) / B;
+    const int4 *faces = c->d_face_src + c->mesh_face_base[mesh];
+    hipLaunchKernelGGL(pt::centroid_bounds_kernel, dim3(G < 128 ? G : 128), dim3(B), 0, st, c->d_verts, faces, n,
+                       c->d_centroids, c->d_cbounds);
+    hipLaunchKernelGGL(pt::morton_kernel, dim3(G), dim3(B), 0, st, c->d_centroids, c->d_cbounds, n, c->d_sort_keys[0],
+                       c->d_sort_vals[0]);
+    const int wg = (n_waves + pt::RS_BLOCK / 64 - 1) / (pt::RS_BLOCK / 64);
+    int cur = 0;
+    for (int shift = 0; shift < 32; shift += 8) { // the top pass only sees bits 24..29 of the 30-bit code
+        hipLaunchKernelGGL(pt::rs_hist_kernel, dim3(wg), dim3(pt::RS_BLOCK), 0, st, c->d_sort_keys[cur], n, shift,
+                           c->d_sort_hist, n_waves);
+        uint32_t *positions = c->d_sort_hist + (size_t)n_waves * 256;
+        hipLaunchKernelGGL(pt::rs_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_sort_hist, positions, n_waves);
+        hipLaunchKernelGGL(pt::rs_scatter_kernel, dim3(wg), dim3(pt::RS_BLOCK), 0, st, c->d_sort_keys[cur],
+                           c->d_sort_vals[cur], n, shift, positions, n_waves, c->d_sort_keys[cur ^ 1],
+                           c->d_sort_vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(pt::apply_order_kernel, dim3(G), dim3(B), 0, st, c->d_sort_vals[cur], c->d_slot_pos, faces,
+                       c->d_slot_face, c->mesh_slot_base[mesh], n, c->d_cbounds);
+    HIP_TRY(c, hipGetLastError());
+    return PTRT_OK;
+}
+
+template <class F> int run_graphed(ptrt_ctx *c, int key, F enqueue) {
+    if (!c->use_graphs)
+        return enqueue(c->stream);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        if (!c->capture_stream)
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue(c->capture_stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->capture_stream, &g);
+        if (rc != PTRT_OK || e != hipSuccess || !g) {
+            if (g)
+                (void)hipGraphDestroy(g);
+            return rc != PTRT_OK ? rc : fail(c, PTRT_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess)
+            return fail(c, PTRT_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+        it = c->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
+    return PTRT_OK;
 }
 
 void free_denoiser(ptrt_ctx *c) {
@@ -579,6 +684,8 @@ void ptrt_destroy(ptrt_ctx *c) {
     for (auto &ev : c->ev_ring)
         if (ev)
             (void)hipEventDestroy(ev);
+    if (c->capture_stream)
+        (void)hipStreamDestroy(c->capture_stream);
     if (c->own_stream)
         (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -954,23 +1061,7 @@ int ptrt_refit(ptrt_ctx *c) {
         return fail(c, PTRT_E_INVALID, "ptrt_refit: needs a single-leaf TLAS; rebuild and re-upload instead");
     if (int rc = set_device(c))
         return rc;
-    const int B = 256;
-    if (c->n_slots > 0)
-        hipLaunchKernelGGL(pt::repack_tris_kernel, dim3((c->n_slots + B - 1) / B), dim3(B), 0, c->stream, c->d_verts,
-                           c->d_slot_face, c->d_tris, c->n_slots);
-    if (c->n_leaves > 0)
-        hipLaunchKernelGGL(pt::refit_leaves_kernel, dim3((c->n_leaves + B - 1) / B), dim3(B), 0, c->stream, c->d_verts,
-                           c->d_slot_face, c->d_leaves, c->d_leaf_dst, c->d_nodes, c->d_mesh_recs, c->n_leaves);
-    for (int d = (int)c->level_offset.size() - 1; d >= 1; --d) { // depth d nodes: [offset[d-1], offset[d])
-        const int begin = c->level_offset[d - 1], count = c->level_offset[d] - begin;
-        if (count > 0)
-            hipLaunchKernelGGL(pt::refit_level_kernel, dim3((count + B - 1) / B), dim3(B), 0, c->stream,
-                               c->d_level_nodes + begin, count, c->d_node_dst, c->d_nodes, c->d_mesh_recs);
-    }
-    hipLaunchKernelGGL(pt::refit_tlas_root_kernel, dim3(1), dim3(64), 0, c->stream, c->d_mesh_recs, c->d_tlas_leaves,
-                       c->d_tlas_mesh_ids, c->tlas_root_ref, c->d_tlas_root_box);
-    HIP_TRY(c, hipGetLastError());
-    return PTRT_OK;
+    return run_graphed(c, -1, [c](hipStream_t st) { return enqueue_refit(c, st); });
 }
 
 int ptrt_build_bvh(ptrt_ctx *c, int mesh) {
@@ -1000,35 +1091,21 @@ int ptrt_build_bvh(ptrt_ctx *c, int mesh) {
             HIP_TRY(c, hipMalloc((void **)&c->d_sort_keys[k], (size_t)n * 4));
             HIP_TRY(c, hipMalloc((void **)&c->d_sort_vals[k], (size_t)n * 4));
         }
-        HIP_TRY(c, hipMalloc((void **)&c->d_sort_hist, (size_t)n_waves * 256 * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->d_sort_hist, (size_t)n_waves * 256 * 4 * 2)); // counts | positions
         HIP_TRY(c, hipMalloc((void **)&c->d_centroids, (size_t)n * 12));
-        if (!c->d_cbounds)
+        if (!c->d_cbounds) { // min words all-ones, max words zero; every build leaves them so again
             HIP_TRY(c, hipMalloc((void **)&c->d_cbounds, 6 * 4));
+            HIP_TRY(c, hipMemsetAsync(c->d_cbounds, 0xff, 12, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_cbounds + 3, 0, 12, c->stream));
+        }
         c->sort_capacity = n;
+        drop_graphs(c); // captured launches hold the old scratch pointers
     }
-    const int B = 256, G = (n + B - 1) / B;
-    const int4 *faces = c->d_face_src + c->mesh_face_base[mesh];
-    HIP_TRY(c, hipMemsetAsync(c->d_cbounds, 0xff, 12, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_cbounds + 3, 0, 12, c->stream));
-    hipLaunchKernelGGL(pt::centroid_bounds_kernel, dim3(G), dim3(B), 0, c->stream, c->d_verts, faces, n, c->d_centroids,
-                       c->d_cbounds);
-    hipLaunchKernelGGL(pt::morton_kernel, dim3(G), dim3(B), 0, c->stream, c->d_centroids, c->d_cbounds, n, c->d_sort_keys[0],
-                       c->d_sort_vals[0]);
-    const int wg = (n_waves + pt::RS_BLOCK / 64 - 1) / (pt::RS_BLOCK / 64);
-    int cur = 0;
-    for (int shift = 0; shift < 32; shift += 8) { // the top pass only sees bits 24..29 of the 30-bit code
-        hipLaunchKernelGGL(pt::rs_hist_kernel, dim3(wg), dim3(pt::RS_BLOCK), 0, c->stream, c->d_sort_keys[cur], n, shift,
-                           c->d_sort_hist, n_waves);
-        hipLaunchKernelGGL(pt::rs_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_sort_hist, n_waves * 256);
-        hipLaunchKernelGGL(pt::rs_scatter_kernel, dim3(wg), dim3(pt::RS_BLOCK), 0, c->stream, c->d_sort_keys[cur],
-                           c->d_sort_vals[cur], n, shift, c->d_sort_hist, n_waves, c->d_sort_keys[cur ^ 1],
-                           c->d_sort_vals[cur ^ 1]);
-        cur ^= 1;
-    }
-    hipLaunchKernelGGL(pt::apply_order_kernel, dim3(G), dim3(B), 0, c->stream, c->d_sort_vals[cur], c->d_slot_pos, faces,
-                       c->d_slot_face, c->mesh_slot_base[mesh], n);
-    HIP_TRY(c, hipGetLastError());
-    return ptrt_refit(c);
+    return run_graphed(c, mesh, [c, mesh](hipStream_t st) {
+        if (int rc = enqueue_build(c, mesh, st))
+            return rc;
+        return enqueue_refit(c, st);
+    });
 }
 
 int ptrt_update_triangles(ptrt_ctx *c, int mesh, const float *verts9, int tri_count, int on_device) {
@@ -1421,6 +1498,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->dn_active = value ? 1 : 0;
     else if (n == "motion_vectors") // perfSettings.enableMotionVectors
         c->mv_active = value ? 1 : 0;
+    else if (n == "use_graphs") // 0: issue the refit / rebuild launches one by one instead of replaying a hipGraph
+        c->use_graphs = value ? 1 : 0;
     else
         return fail(c, PTRT_E_INVALID, "unknown option '%s'", name);
     return PTRT_OK;

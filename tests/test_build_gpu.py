@@ -62,7 +62,8 @@ def test_rebuild_sorts_faces_in_morton_order_and_frames_match_the_oracle(P, O, b
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 1)
     assert_frames_equal(gpu, cpu)
     host_order = s.primIndices(w).copy()
-    for t in (0.6, 1.7):
+    for t, graphs in ((0.6, 1), (1.1, 1), (1.7, 0)):     # captured-graph replay (twice) and plain launches
+        s.set_option("use_graphs", graphs)
         s.setVertices(w, P.scenes.water_vertices(40, t))
         s.rebuildObjectChanges()
         verts, faces = mesh_arrays(P, s, w)

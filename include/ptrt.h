@@ -165,7 +165,11 @@ enum {
     PTRT_BUF_RGB8 = 4,      /* uint8[rows*W*3]  tonemapped tile, bottom-up WITHIN the tile                 */
     PTRT_BUF_RNG = 5,       /* uint32[rows*W*6] generator state {d, v0..v4} per pixel (canonical order)     */
     PTRT_BUF_DENOISED = 6,  /* float[H*W*3]     denoiser output (d_denoised_buffer, scene.cuh:1121); denoiser on */
-    PTRT_BUF_MOTION = 7     /* float[H*W*2]     uv motion vectors, Scene::getMotionVectorBuffer (scene.cuh:1725)  */
+    PTRT_BUF_MOTION = 7,    /* float[H*W*2]     uv motion vectors, Scene::getMotionVectorBuffer (scene.cuh:1725)  */
+    PTRT_BUF_RENDER_ACCUM = 8 /* float[rh*rw*3] the path tracer's colour image at the render size: d_scaled_accum
+                                 (scene.cuh:181) after ptrt_set_render_size, else the same memory as ACCUM.  With a
+                                 reduced render size NORMAL/DEPTH/OBJECT_ID/DENOISED/MOTION are rw x rh as well
+                                 (the d_scaled_* set) and ACCUM holds the up-scaled final HDR image (scene.cuh:1194). */
 };
 
 typedef struct ptrt_ctx ptrt_ctx;
@@ -274,12 +278,29 @@ int ptrt_denoiser_disable(ptrt_ctx *ctx);
  * mat4 stores them (column-major), consumed by the next ptrt_render's motion-vector pass. */
 int ptrt_set_prev_view_proj(ptrt_ctx *ctx, const float *m16);
 
+/* ---- post-process "next" row: bloom + resolution scale ----
+ * perfSettings.enableBloom (scene.cuh:1137-1183): bright pass (threshold 1.5, knee 0.5), six
+ * levels of 5-tap horizontal blur + 5-tap vertical down-sample, five bilinear up-sample-adds,
+ * and the last up-sample-add INTO the frame's HDR image (the noisy colour buffer, or the denoised
+ * one when the denoiser runs), before the tonemap.  Same arithmetic and the same mip sizes as
+ * the reference's host loop, in 8 launches instead of 19 (pt_post.hip.h).  Needs a full-frame
+ * context of at least 64x64 (below that a mip level is empty and the reference reads NULL). */
+int ptrt_set_bloom(ptrt_ctx *ctx, int enabled);
+/* Scene::updateScaledBuffers (scene.cuh:1913-2000) for perfSettings.resolutionScale: path trace,
+ * motion vectors, denoiser and bloom run at render_w x render_h (the d_scaled_* buffers; pixel p
+ * of the small frame continues generator state p, as the reference's launch does), then
+ * upscale_bilinear_kernel (scene_kernels.cuh:406-441) fills the full-size colour buffer, which is
+ * tonemapped.  Changing the size frees the denoiser (re-enable it; the reference re-creates it at
+ * the new size) -- the caller also restarts accumulation.  The Scene wrapper computes
+ * render_w = max(64, int(W * scale)) like the reference.  Full-frame contexts only. */
+int ptrt_set_render_size(ptrt_ctx *ctx, int render_w, int render_h);
+
 /* convenience: the five uploads above from one flattened description */
 int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);
 
-/* The body of Scene::render_to_device (scene.cuh:1028-1209) with denoiser, bloom
- * and upscale off: path_trace_kernel then tonemap_kernel for this context's
- * tile.  `frame_index` is the reference's frame_count_ (jitter index frame+s,
+/* The body of Scene::render_to_device (scene.cuh:1028-1209): path_trace_kernel, then -- for
+ * full-frame contexts that enabled them -- motion vectors + denoiser, bloom, up-scale, and the
+ * tonemap of the final HDR image (fused into whichever stage produces it).  `frame_index` is the reference's frame_count_ (jitter index frame+s,
  * scene_kernels.cuh:152-157).  `out_rgb8`: tile_rows*W*3 bytes, bottom-up within
  * the tile; a DEVICE pointer if out_is_device != 0 (the mapped PBO of
  * glfw_view_interop.hpp:281), else a host buffer (synchronous copy).  NULL skips

@@ -194,6 +194,29 @@ def motion_vectors(depth, width, height, camera, prev_view_proj):
     return out
 
 
+lib.oracle_bloom.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int]
+lib.oracle_bloom.restype = C.c_int
+lib.oracle_upscale.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int]
+
+
+def bloom(image, width, height, alloc_w=None, alloc_h=None):
+    """Step 5 of Scene::render_to_device (bright pass, 6-level blur/downsample chain, upsample-adds) on a
+    (height*width, 3) image; returns the image with bloom added."""
+    img = np.ascontiguousarray(image, np.float32).copy()
+    rc = lib.oracle_bloom(_f(img), width, height, alloc_w or width, alloc_h or height)
+    if rc != 0:
+        raise RuntimeError("oracle_bloom: a mip level has zero size (the reference dereferences NULL there)")
+    return img
+
+
+def upscale(image, out_w, out_h, in_w, in_h):
+    """upscale_bilinear_kernel."""
+    src = np.ascontiguousarray(image, np.float32)
+    out = np.zeros((out_w * out_h, 3), np.float32)
+    lib.oracle_upscale(_f(out), _f(src), out_w, out_h, in_w, in_h)
+    return out
+
+
 def detmath(op, x, y=None):
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)

@@ -382,12 +382,14 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
     }
     if (LAST) {
         st3(out3, idx, res);
-        unsigned char r, gg, b;
-        tonemap_pixel(res, r, gg, b);
-        const size_t o = ((size_t)(H - 1 - y) * W + x) * 3;
-        rgb8[o] = r;
-        rgb8[o + 1] = gg;
-        rgb8[o + 2] = b;
+        if (rgb8) { // NULL when bloom / up-scale follow and tonemap their own result
+            unsigned char r, gg, b;
+            tonemap_pixel(res, r, gg, b);
+            const size_t o = ((size_t)(H - 1 - y) * W + x) * 3;
+            rgb8[o] = r;
+            rgb8[o + 1] = gg;
+            rgb8[o + 2] = b;
+        }
     } else {
         out_c4[idx] = mk4(res, res_var);
     }
@@ -399,6 +401,8 @@ __global__ __launch_bounds__(256) void c4_to_output_kernel(const float4 *__restr
     PT_PIXEL_XY
     const f3 res = xyz(in_c4[idx]);
     st3(out3, idx, res);
+    if (!rgb8)
+        return;
     unsigned char r, g, b;
     tonemap_pixel(res, r, g, b);
     const size_t o = ((size_t)(H - 1 - y) * W + x) * 3;

@@ -79,7 +79,8 @@ struct KParams {
     int tiles_x;
     int spp, max_depth, frame_count;
     // buffers (tile-sized)
-    uint32_t *rng; // 6 planes of rows*width
+    uint32_t *rng;    // 6 planes of rng_plane words (the context's rows*width; larger than the frame at a reduced render size)
+    size_t rng_plane;
     float *accum, *normal, *depth;
     int *object_id;
     unsigned char *rgb8;

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     const int yl = ty * 8 + (lane >> 3);
     const bool inside = (x < K.width) && (yl < K.rows);
     const int y = K.y0 + yl;
-    const size_t npix = (size_t)K.rows * K.width;
+    const size_t npix = K.rng_plane;
     const size_t idx = (size_t)yl * K.width + x;
 
     Rng rng = {0, 0, 0, 0, 0, 0};
@@ -589,13 +589,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         K.accum[idx * 3 + 0] = out.x;
         K.accum[idx * 3 + 1] = out.y;
         K.accum[idx * 3 + 2] = out.z;
-        // tonemap_kernel fused: RGB8, rows flipped within the tile (scene.cuh:2013-2015)
-        unsigned char r8, g8, b8;
-        tonemap_pixel(out, r8, g8, b8);
-        const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
-        K.rgb8[o + 0] = r8;
-        K.rgb8[o + 1] = g8;
-        K.rgb8[o + 2] = b8;
+        // tonemap_kernel fused: RGB8, rows flipped within the tile (scene.cuh:2013-2015); skipped
+        // (wave-uniform) when a denoiser / bloom / up-scale stage follows and tonemaps its own result
+        if (K.rgb8) {
+            unsigned char r8, g8, b8;
+            tonemap_pixel(out, r8, g8, b8);
+            const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
+            K.rgb8[o + 0] = r8;
+            K.rgb8[o + 1] = g8;
+            K.rgb8[o + 2] = b8;
+        }
     }
     if (K.counters) {
         uint32_t a = n_ext, b = n_shadow, c = inside ? (uint32_t)K.spp : 0u;

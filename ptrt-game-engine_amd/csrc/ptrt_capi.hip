@@ -9,6 +9,7 @@
 #include "../../include/ptrt.h"
 #include "pt_build.hip.h"
 #include "pt_denoise.hip.h"
+#include "pt_post.hip.h"
 #include "pt_refit.hip.h"
 #include "pt_render.hip.h"
 
@@ -106,6 +107,15 @@ struct ptrt_ctx {
     int dn_cur = 0; // which history set holds the latest result
     int dn_active = 1, mv_active = 1;
     float prev_view_proj[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
+    // post chain (pt_post.hip.h): render size (perfSettings.resolutionScale) and bloom
+    int rw = 0, rh = 0; // render size; == W,H unless ptrt_set_render_size asked for less
+    float *s_accum = nullptr, *s_normal = nullptr, *s_depth = nullptr; // the d_scaled_* set (scene.cuh:181-186)
+    int *s_object_id = nullptr;
+    int bloom_on = 0;
+    float *bl_mip[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // d_bloom_mip_chain (scene.cuh:161, 809-822)
+    bool scaled() const { return rw != W || rh != H; }
+    size_t rpix() const { return scaled() ? (size_t)rw * rh : npix; } // pixels the path tracer renders
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1;
@@ -367,16 +377,20 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.sky_top = c->sky_top;
     K.sky_bottom = c->sky_bottom;
     K.use_sky = c->use_sky;
-    K.width = c->W;
-    K.height = c->H;
+    // at a reduced render size (full-frame contexts only) the frame is rw x rh in the d_scaled_* set; the
+    // generator states stay where they are: pixel p of the small frame uses state p (scene.cuh:1091-1098)
+    const bool scaled = c->scaled();
+    K.width = c->rw;
+    K.height = c->rh;
     K.y0 = c->y0;
-    K.rows = c->rows;
-    K.tiles_x = (c->W + 7) / 8;
+    K.rows = scaled ? c->rh : c->rows;
+    K.tiles_x = (c->rw + 7) / 8;
     K.rng = c->d_rng;
-    K.accum = c->d_accum;
-    K.normal = c->d_normal;
-    K.depth = c->d_depth;
-    K.object_id = c->d_object_id;
+    K.rng_plane = c->npix;
+    K.accum = scaled ? c->s_accum : c->d_accum;
+    K.normal = scaled ? c->s_normal : c->d_normal;
+    K.depth = scaled ? c->s_depth : c->d_depth;
+    K.object_id = scaled ? c->s_object_id : c->d_object_id;
     K.rgb8 = c->d_rgb8;
     K.counters = nullptr;
     return K;
@@ -537,34 +551,34 @@ void free_denoiser(ptrt_ctx *c) {
 // swap of the double-buffered sets (history moments AND the packed G-buffer); no device copies.
 // 3 + atrous_iterations launches per frame: prep, temporal, variance, a-trous x N (the last one
 // also writes the API's vec3 image and the RGB8 frame).
-int run_denoiser(ptrt_ctx *c, unsigned char *rgb8) {
-    const int W = c->W, H = c->H;
+int run_denoiser(ptrt_ctx *c, const pt::KParams &K, unsigned char *rgb8) {
+    const int W = c->rw, H = c->rh; // the render size (the denoiser was allocated for it)
     const dim3 grid((W + 63) / 64, (H + 3) / 4), block(256);
     const pt::DenoiseSettings &S = c->dn;
     const int prev = c->dn_cur, next = c->dn_cur ^ 1;
     // perfSettings.enableMotionVectors (scene.cuh:1103); when off the last vectors are reused
     if (c->mv_active)
         HIP_TRY(c, hipMemcpyAsync(c->dn_pvp, c->prev_view_proj, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pt::prep_kernel, grid, block, 0, c->stream, c->dn_g4[next], c->dn_motion, c->dn_cur4, c->d_accum,
-                       c->d_normal, c->d_depth, W, H, c->cam.origin, c->cam.llc, c->cam.horizontal, c->cam.vertical,
+    hipLaunchKernelGGL(pt::prep_kernel, grid, block, 0, c->stream, c->dn_g4[next], c->dn_motion, c->dn_cur4, K.accum,
+                       K.normal, K.depth, W, H, c->cam.origin, c->cam.llc, c->cam.horizontal, c->cam.vertical,
                        c->dn_pvp, c->mv_active, S.sky_depth_threshold, S.enable_firefly_suppression);
     hipLaunchKernelGGL(pt::temporal_kernel, grid, block, 0, c->stream, c->dn_h1[next], c->dn_h2[next], c->dn_cur4,
-                       c->dn_h1[prev], c->dn_h2[prev], c->dn_motion, c->dn_g4[next], c->dn_g4[prev], c->d_object_id,
+                       c->dn_h1[prev], c->dn_h2[prev], c->dn_motion, c->dn_g4[next], c->dn_g4[prev], K.object_id,
                        c->dn_hobj, S, c->dn_first ? 1 : 0, W, H);
     c->dn_cur = next;
     hipLaunchKernelGGL(pt::variance_kernel, grid, block, 0, c->stream, c->dn_c4[0], c->dn_h1[next], c->dn_h2[next],
-                       c->dn_g4[next], c->d_object_id, c->dn_hobj, S.sky_depth_threshold, S.use_object_ids, W, H);
+                       c->dn_g4[next], K.object_id, c->dn_hobj, S.sky_depth_threshold, S.use_object_ids, W, H);
     const int steps[5] = {1, 2, 4, 8, 16};
     const int iters = S.atrous_iterations < 5 ? (S.atrous_iterations < 0 ? 0 : S.atrous_iterations) : 5;
     for (int i = 0; i < iters; ++i) {
         const float4 *in = c->dn_c4[i & 1];
         float4 *out = c->dn_c4[(i + 1) & 1];
         if (i == iters - 1)
-            hipLaunchKernelGGL(pt::atrous_kernel<true>, grid, block, 0, c->stream, out, in, c->dn_g4[next], c->d_object_id,
+            hipLaunchKernelGGL(pt::atrous_kernel<true>, grid, block, 0, c->stream, out, in, c->dn_g4[next], K.object_id,
                                steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
                                S.edge_normal_threshold, S.use_object_ids, W, H, c->dn_out, rgb8);
         else
-            hipLaunchKernelGGL(pt::atrous_kernel<false>, grid, block, 0, c->stream, out, in, c->dn_g4[next], c->d_object_id,
+            hipLaunchKernelGGL(pt::atrous_kernel<false>, grid, block, 0, c->stream, out, in, c->dn_g4[next], K.object_id,
                                steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
                                S.edge_normal_threshold, S.use_object_ids, W, H, (float *)nullptr, (unsigned char *)nullptr);
     }
@@ -573,6 +587,58 @@ int run_denoiser(ptrt_ctx *c, unsigned char *rgb8) {
     HIP_TRY(c, hipGetLastError());
     c->dn_first = false;
     return PTRT_OK;
+}
+
+// Step 5 of Scene::render_to_device (scene.cuh:1137-1183) on `image` (w x h, in place), with the
+// reference's own pass list and sizes (see pt_post.hip.h); `rgb8` non-NULL: also tonemap the result.
+int run_bloom(ptrt_ctx *c, float *image, int w, int h, unsigned char *rgb8) {
+    std::vector<pt::BloomPass> passes;
+    int mip_w = w, mip_h = h;
+    const float *last = image;
+    for (int i = 0; i < 6; ++i) {
+        const int next_w = mip_w / 2, next_h = mip_h / 2;
+        passes.push_back(pt::BloomPass{i == 0 ? 0 : 1, c->bl_mip[i], last, mip_w, mip_h, next_w, next_h});
+        last = c->bl_mip[i];
+        mip_w = next_w;
+        mip_h = next_h;
+    }
+    for (int i = 4; i >= 0; --i) {
+        mip_w *= 2;
+        mip_h *= 2;
+        passes.push_back(pt::BloomPass{2, c->bl_mip[i], c->bl_mip[i + 1], mip_w / 2, mip_h / 2, (mip_w / 2) * 2, (mip_h / 2) * 2});
+    }
+    const bool fuse_final = (w % 2) == 0; // else the reference's row stride 2*(w/2) is not the frame's
+    if (!fuse_final)
+        passes.push_back(pt::BloomPass{2, image, c->bl_mip[0], w / 2, h / 2, (w / 2) * 2, (h / 2) * 2});
+    for (size_t k = 0; k < passes.size();) {
+        auto small = [&](size_t i) { return (size_t)passes[i].out_w * passes[i].out_h <= 16384; };
+        if (small(k)) {
+            pt::BloomSmallPasses S{};
+            while (k < passes.size() && small(k) && S.n < 8)
+                S.p[S.n++] = passes[k++];
+            hipLaunchKernelGGL(pt::bloom_small_passes_kernel, dim3(1), dim3(1024), 0, c->stream, S);
+        } else {
+            const pt::BloomPass &P = passes[k++];
+            hipLaunchKernelGGL(pt::bloom_pass_kernel, dim3((P.out_w + 63) / 64, (P.out_h + 3) / 4), dim3(256), 0, c->stream, P);
+        }
+    }
+    const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+    if (fuse_final)
+        hipLaunchKernelGGL(pt::bloom_final_kernel, grid, block, 0, c->stream, image, c->bl_mip[0], w, h, w / 2, h / 2, rgb8);
+    else if (rgb8)
+        hipLaunchKernelGGL(pt::tonemap_only_kernel, grid, block, 0, c->stream, rgb8, image, w, h);
+    HIP_TRY(c, hipGetLastError());
+    return PTRT_OK;
+}
+
+void free_post(ptrt_ctx *c) {
+    dfree(c->s_accum);
+    dfree(c->s_normal);
+    dfree(c->s_depth);
+    dfree(c->s_object_id);
+    for (int i = 0; i < 6; ++i)
+        dfree(c->bl_mip[i]);
+    c->bloom_on = 0;
 }
 
 } // namespace
@@ -615,6 +681,8 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
     c->y0 = tile_y0;
     c->rows = tile_rows;
     c->npix = (size_t)full_w * tile_rows;
+    c->rw = full_w;
+    c->rh = full_h;
     {
         std::lock_guard<std::mutex> lock(g_live_mutex);
         g_live.insert(c);
@@ -681,6 +749,7 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_blue);
     dfree(c->d_jump);
     free_denoiser(c);
+    free_post(c);
     for (auto &ev : c->ev_ring)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -1195,7 +1264,7 @@ int ptrt_denoiser_enable(ptrt_ctx *c, const ptrt_denoiser_settings *s) {
         d = *s;
     free_denoiser(c);
     std::memcpy(&c->dn, &d, sizeof d);
-    const size_t n = c->npix;
+    const size_t n = c->rpix(); // "(re)create at current render resolution" (scene.cuh:1984-1996)
     HIP_TRY(c, hipMalloc((void **)&c->dn_cur4, n * 16));
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(c, hipMalloc((void **)&c->dn_c4[k], n * 16));
@@ -1233,6 +1302,65 @@ int ptrt_set_prev_view_proj(ptrt_ctx *c, const float *m16) {
     return PTRT_OK;
 }
 
+int ptrt_set_render_size(ptrt_ctx *c, int render_w, int render_h) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_set_render_size: bad context");
+    if (render_w == c->rw && render_h == c->rh)
+        return PTRT_OK;
+    if (c->rows != c->H || c->y0 != 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_render_size: only full-frame contexts can render at a reduced size");
+    if (render_w < 1 || render_h < 1 || render_w > c->W || render_h > c->H)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_render_size: %dx%d is not within 1x1 .. %dx%d", render_w, render_h, c->W, c->H);
+    if (c->bloom_on && (render_w < 64 || render_h < 64))
+        return fail(c, PTRT_E_INVALID, "ptrt_set_render_size: bloom needs at least 64x64 (six mip levels)");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->s_accum);
+    dfree(c->s_normal);
+    dfree(c->s_depth);
+    dfree(c->s_object_id);
+    free_denoiser(c); // its images have the old size; the caller re-enables it (Scene::updateScaledBuffers does)
+    c->rw = render_w;
+    c->rh = render_h;
+    if (c->scaled()) {
+        const size_t n = c->rpix();
+        HIP_TRY(c, hipMalloc((void **)&c->s_accum, n * 12));
+        HIP_TRY(c, hipMalloc((void **)&c->s_normal, n * 12));
+        HIP_TRY(c, hipMalloc((void **)&c->s_depth, n * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->s_object_id, n * 4));
+        HIP_TRY(c, hipMemsetAsync(c->s_accum, 0, n * 12, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PTRT_OK;
+}
+
+int ptrt_set_bloom(ptrt_ctx *c, int enabled) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_set_bloom: bad context");
+    if (!enabled) {
+        c->bloom_on = 0; // the mips stay allocated, as in the reference
+        return PTRT_OK;
+    }
+    if (c->rows != c->H || c->y0 != 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_bloom: bloom needs a full-frame context (its blur reads across band "
+                                       "borders); apply it on the presenting rank instead");
+    if (c->rw < 64 || c->rh < 64)
+        return fail(c, PTRT_E_INVALID, "ptrt_set_bloom: bloom needs at least 64x64 pixels: below that one of the six mip "
+                                       "levels is empty (the reference would read a NULL mip, scene.cuh:812-816,1175)");
+    if (int rc = set_device(c))
+        return rc;
+    int mw = c->W, mh = c->H;
+    for (int i = 0; i < 6; ++i) { // scene.cuh:809-822: sized from the FULL frame
+        mw /= 2;
+        mh /= 2;
+        if (!c->bl_mip[i])
+            HIP_TRY(c, hipMalloc((void **)&c->bl_mip[i], (size_t)mw * mh * 12));
+    }
+    c->bloom_on = 1;
+    return PTRT_OK;
+}
+
 int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
     if (!ctx_live(c))
         return fail(c, PTRT_E_INVALID, "ptrt_render: bad context");
@@ -1250,11 +1378,14 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     K.spp = spp;
     K.max_depth = max_depth;
     K.frame_count = frame_index;
-    K.rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
-    c->last_rgb8 = K.rgb8;
+    unsigned char *frame_rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
+    c->last_rgb8 = frame_rgb8;
+    // the stage that produces the final HDR image also tonemaps it; earlier stages skip theirs
+    const bool scaled = c->scaled(), denoise = c->dn_on && c->dn_active, bloom = c->bloom_on != 0;
+    K.rgb8 = (denoise || bloom || scaled) ? nullptr : frame_rgb8;
     if (c->count_rays)
         K.counters = c->d_counters;
-    const int tiles_y = (c->rows + 7) / 8;
+    const int tiles_y = (K.rows + 7) / 8;
     const int grid = K.tiles_x * tiles_y;
     const int geom = pick_geom(c);
     const bool full = c->mats_full || c->force_full;
@@ -1276,9 +1407,20 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     c->launches++;
     c->timed = true;
-    if (c->dn_on && c->dn_active) {
-        if (int rc = run_denoiser(c, K.rgb8))
+    float *current = K.accum; // `current_image` of Scene::render_to_device (scene.cuh:1086)
+    if (denoise) {
+        if (int rc = run_denoiser(c, K, (bloom || scaled) ? nullptr : frame_rgb8))
             return rc;
+        current = c->dn_out;
+    }
+    if (bloom) {
+        if (int rc = run_bloom(c, current, c->rw, c->rh, scaled ? nullptr : frame_rgb8))
+            return rc;
+    }
+    if (scaled) { // up-scale into the full-size colour buffer (scene.cuh:1192-1201) + tonemap
+        hipLaunchKernelGGL(pt::upscale_tonemap_kernel, dim3((c->W + 63) / 64, (c->H + 3) / 4), dim3(256), 0, c->stream,
+                           c->d_accum, current, c->W, c->H, c->rw, c->rh, frame_rgb8);
+        HIP_TRY(c, hipGetLastError());
     }
     if (out_rgb8 && !out_is_device) {
         HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
@@ -1345,9 +1487,10 @@ void *ptrt_device_buffer(ptrt_ctx *c, int kind) {
         return nullptr;
     switch (kind) {
     case PTRT_BUF_ACCUM: return c->d_accum;
-    case PTRT_BUF_NORMAL: return c->d_normal;
-    case PTRT_BUF_DEPTH: return c->d_depth;
-    case PTRT_BUF_OBJECT_ID: return c->d_object_id;
+    case PTRT_BUF_NORMAL: return c->scaled() ? c->s_normal : c->d_normal;
+    case PTRT_BUF_DEPTH: return c->scaled() ? c->s_depth : c->d_depth;
+    case PTRT_BUF_OBJECT_ID: return c->scaled() ? c->s_object_id : c->d_object_id;
+    case PTRT_BUF_RENDER_ACCUM: return c->scaled() ? c->s_accum : c->d_accum;
     case PTRT_BUF_RGB8: return c->last_rgb8;
     case PTRT_BUF_DENOISED: return c->dn_on ? c->dn_out : nullptr;
     case PTRT_BUF_MOTION: return c->dn_on ? c->dn_motion : nullptr;
@@ -1363,17 +1506,20 @@ int ptrt_read_buffer(ptrt_ctx *c, int kind, void *dst, size_t bytes) {
     size_t need = 0;
     const void *src = nullptr;
     switch (kind) {
+    // G-buffers, denoiser images and RENDER_ACCUM hold render-size frames (== the frame size unless
+    // ptrt_set_render_size reduced it); ACCUM is the full-size HDR image that was tonemapped
     case PTRT_BUF_ACCUM: need = c->npix * 12; src = c->d_accum; break;
-    case PTRT_BUF_NORMAL: need = c->npix * 12; src = c->d_normal; break;
-    case PTRT_BUF_DEPTH: need = c->npix * 4; src = c->d_depth; break;
-    case PTRT_BUF_OBJECT_ID: need = c->npix * 4; src = c->d_object_id; break;
+    case PTRT_BUF_RENDER_ACCUM: need = c->rpix() * 12; src = c->scaled() ? c->s_accum : c->d_accum; break;
+    case PTRT_BUF_NORMAL: need = c->rpix() * 12; src = c->scaled() ? c->s_normal : c->d_normal; break;
+    case PTRT_BUF_DEPTH: need = c->rpix() * 4; src = c->scaled() ? c->s_depth : c->d_depth; break;
+    case PTRT_BUF_OBJECT_ID: need = c->rpix() * 4; src = c->scaled() ? c->s_object_id : c->d_object_id; break;
     case PTRT_BUF_RGB8: need = c->npix * 3; src = c->last_rgb8; break;
     case PTRT_BUF_RNG: need = c->npix * 24; break;
     case PTRT_BUF_DENOISED:
     case PTRT_BUF_MOTION:
         if (!c->dn_on)
             return fail(c, PTRT_E_NOT_READY, "ptrt_read_buffer: the denoiser is not enabled");
-        need = c->npix * (kind == PTRT_BUF_DENOISED ? 12 : 8);
+        need = c->rpix() * (kind == PTRT_BUF_DENOISED ? 12 : 8);
         src = kind == PTRT_BUF_DENOISED ? c->dn_out : c->dn_motion;
         break;
     default: return fail(c, PTRT_E_INVALID, "ptrt_read_buffer: unknown kind %d", kind);

@@ -200,9 +200,14 @@ void hs_disable_sky(void *s) { static_cast<Scene *>(s)->disableSky(); }
 void hs_set_bvh_leaf_target(void *s, int target, int tol) { static_cast<Scene *>(s)->setBVHLeafTarget(target, tol); }
 void hs_set_max_bounce_depth(void *s, int d) { static_cast<Scene *>(s)->setMaxBounceDepth(d); }
 void hs_set_samples_per_pixel(void *s, int spp) { static_cast<Scene *>(s)->setSamplesPerPixel(spp); }
-void hs_set_denoiser_enabled(void *s, int e) { static_cast<Scene *>(s)->setDenoiserEnabled(e != 0); }
+int hs_set_denoiser_enabled(void *s, int e) { HS_TRY(static_cast<Scene *>(s)->setDenoiserEnabled(e != 0)); return 0; }
 void hs_set_bloom_enabled(void *s, int e) { static_cast<Scene *>(s)->setBloomEnabled(e != 0); }
-void hs_set_performance_preset(void *s, const char *name) { static_cast<Scene *>(s)->setPerformancePreset(name); }
+int hs_set_performance_preset(void *s, const char *name) { HS_TRY(static_cast<Scene *>(s)->setPerformancePreset(name)); return 0; }
+int hs_set_resolution_scale(void *s, float scale) { HS_TRY(static_cast<Scene *>(s)->setResolutionScale(scale)); return 0; }
+void hs_get_render_size(void *s, int *w, int *h) {
+    *w = static_cast<Scene *>(s)->getRenderWidth();
+    *h = static_cast<Scene *>(s)->getRenderHeight();
+}
 void hs_get_settings(void *s, int *spp, int *depth, int *denoiser, int *bloom, float *scale) {
     const Scene::PerformanceSettings &p = static_cast<Scene *>(s)->getPerformanceSettings();
     *spp = p.samplesPerPixel;

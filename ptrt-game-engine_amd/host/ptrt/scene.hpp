@@ -218,6 +218,8 @@ class Scene {
     Scene(int w, int h, int tile_y0 = 0, int tile_rows = 0, int device = 0)
         : width(w), height(h), camera(static_cast<float>(w) / h, 2.0f, 1.0f) {
         tileRows = tile_rows > 0 ? tile_rows : h;
+        render_width = w;
+        render_height = h;
         if (device < 0)
             return; // host-only scene: build/flatten/inspect, no back end (every GPU call then fails loudly)
         int rc = ptrt_create(w, h, tile_y0, tile_rows, device, &ctx);
@@ -231,6 +233,7 @@ class Scene {
         if (tileRows == h && tile_y0 == 0) {
             // `denoiser_ = new Denoiser(settings)` (scene.cuh:1984-1993): exists from construction,
             // used while perfSettings.enableDenoiser; band contexts cannot denoise (filters cross bands)
+            fullFrame = true;
             check(ptrt_denoiser_enable(ctx, nullptr), "Failed to create denoiser");
             denoiserAllocated = true;
         }
@@ -553,15 +556,25 @@ class Scene {
         else if (p == "balanced") set(true, true, true, 4, 1.0f, 1);
         else if (p == "performance") set(true, false, true, 3, 0.75f, 1);
         else if (p == "fast") set(false, false, false, 2, 0.35f, 1);
+        updateScaledBuffers();
     }
-    void setDenoiserEnabled(bool e) { perfSettings.enableDenoiser = e; }
+    void setDenoiserEnabled(bool e) {
+        if (perfSettings.enableDenoiser != e) {
+            perfSettings.enableDenoiser = e;
+            updateScaledBuffers(); // a no-op unless the render size changed, as in the reference
+        }
+    }
     void setBloomEnabled(bool e) { perfSettings.enableBloom = e; }
     void setMaxBounceDepth(int d) { perfSettings.maxBounceDepth = d < 1 ? 1 : (d > 16 ? 16 : d); }
     void setResolutionScale(float s) {
         s = fmaxf(0.25f, fminf(1.0f, s));
-        if (fabsf(s - perfSettings.resolutionScale) > 0.01f)
+        if (fabsf(s - perfSettings.resolutionScale) > 0.01f) {
             perfSettings.resolutionScale = s;
+            updateScaledBuffers();
+        }
     }
+    int getRenderWidth() const { return render_width; }
+    int getRenderHeight() const { return render_height; }
     // not in the reference (its samplesPerPixel is only reachable through the
     // "ultra" preset); needed to express the 4-spp benchmark configurations
     void setSamplesPerPixel(int spp) { perfSettings.samplesPerPixel = spp < 1 ? 1 : spp; }
@@ -659,7 +672,36 @@ class Scene {
     ptrt_ctx *ctx = nullptr;
     bool geometryDirty = true, materialsDirty = true, lightsDirty = true, cameraDirty = true, skyDirty = true;
     bool warnedPost = false, denoiserAllocated = false;
+    bool fullFrame = false;                   // band (tile) contexts have no post chain
+    int render_width = 0, render_height = 0;  // scene.cuh:203-204
     mat4 prev_view_proj; // proj*view of the previous frame (scene.cuh:113)
+
+    // scene.cuh:1913-2000: the size the path tracer renders at follows perfSettings.resolutionScale
+    // (>= 64, and here also <= the frame); when it changes, the low-resolution buffers and the
+    // denoiser are re-created (the denoiser only if enabled) and accumulation restarts.
+    void updateScaledBuffers() {
+        int nw = static_cast<int>(width * perfSettings.resolutionScale);
+        int nh = static_cast<int>(height * perfSettings.resolutionScale);
+        nw = nw < 64 ? 64 : nw;
+        nh = nh < 64 ? 64 : nh;
+        nw = nw > width ? width : nw;
+        nh = nh > height ? height : nh;
+        if (nw == render_width && nh == render_height)
+            return;
+        if (ctx && !fullFrame)
+            return; // a band context always renders its rows of the full-size frame
+        render_width = nw;
+        render_height = nh;
+        if (ctx) {
+            check(ptrt_set_render_size(ctx, nw, nh), "Failed to resize the render buffers");
+            denoiserAllocated = false; // freed by the resize
+            if (perfSettings.enableDenoiser) {
+                check(ptrt_denoiser_enable(ctx, nullptr), "Failed to create denoiser");
+                denoiserAllocated = true;
+            }
+        }
+        resetAccumulation();
+    }
 
     // flattened arrays handed to the back end
     std::vector<ptrt_mesh_desc> flatMeshes;
@@ -850,14 +892,18 @@ class Scene {
             return;
         }
         const bool denoise = perfSettings.enableDenoiser && denoiserAllocated;
-        if ((perfSettings.enableBloom || perfSettings.resolutionScale != 1.0f ||
-             (perfSettings.enableDenoiser && !denoiserAllocated)) &&
+        // bloom (scene.cuh:1137-1183) needs the whole frame and six non-empty mip levels
+        const bool bloom = perfSettings.enableBloom && fullFrame && render_width >= 64 && render_height >= 64;
+        if (((perfSettings.enableBloom && !bloom) || (!fullFrame && (perfSettings.enableDenoiser ||
+                                                                     perfSettings.resolutionScale != 1.0f))) &&
             !warnedPost) {
-            std::cerr << "NOTE: bloom and resolution scaling are not part of this back end"
-                      << (perfSettings.enableDenoiser && !denoiserAllocated ? ", and a band (tile) context cannot denoise" : "")
-                      << "; those stages are skipped\n";
+            std::cerr << "NOTE: " << (fullFrame ? "bloom needs a frame of at least 64x64 pixels and is skipped\n"
+                                                : "a band (tile) context renders its rows only: denoiser, bloom and "
+                                                  "resolution scaling are skipped (apply them on the presenting rank)\n");
             warnedPost = true;
         }
+        if (fullFrame)
+            check(ptrt_set_bloom(ctx, bloom ? 1 : 0), "bloom");
         if (denoiserAllocated) { // scene.cuh:1103-1127: motion vectors + Denoiser::denoise after the trace
             check(ptrt_set_option(ctx, "denoiser_active", denoise ? 1 : 0), "denoiser option");
             check(ptrt_set_option(ctx, "motion_vectors", (denoise && perfSettings.enableMotionVectors) ? 1 : 0),

@@ -26,7 +26,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 PTRT_OK = 0
-BUF_ACCUM, BUF_NORMAL, BUF_DEPTH, BUF_OBJECT_ID, BUF_RGB8, BUF_RNG, BUF_DENOISED, BUF_MOTION = range(8)
+BUF_ACCUM, BUF_NORMAL, BUF_DEPTH, BUF_OBJECT_ID, BUF_RGB8, BUF_RNG, BUF_DENOISED, BUF_MOTION, BUF_RENDER_ACCUM = range(9)
 DEFAULT_SEED = 12345
 HOST_ONLY = -1
 
@@ -169,9 +169,13 @@ _sig("hs_disable_sky", None, _vp)
 _sig("hs_set_bvh_leaf_target", None, _vp, C.c_int, C.c_int)
 _sig("hs_set_max_bounce_depth", None, _vp, C.c_int)
 _sig("hs_set_samples_per_pixel", None, _vp, C.c_int)
-_sig("hs_set_denoiser_enabled", None, _vp, C.c_int)
+_sig("hs_set_denoiser_enabled", C.c_int, _vp, C.c_int)
 _sig("hs_set_bloom_enabled", None, _vp, C.c_int)
-_sig("hs_set_performance_preset", None, _vp, C.c_char_p)
+_sig("hs_set_performance_preset", C.c_int, _vp, C.c_char_p)
+_sig("hs_set_resolution_scale", C.c_int, _vp, C.c_float)
+_sig("hs_get_render_size", None, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+_sig("ptrt_set_bloom", C.c_int, _vp, C.c_int)
+_sig("ptrt_set_render_size", C.c_int, _vp, C.c_int, C.c_int)
 _sig("hs_get_settings", None, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
      C.POINTER(C.c_int), _fp)
 _sig("hs_set_mesh_material", C.c_int, _vp, C.c_int, _fp)
@@ -343,9 +347,16 @@ class Scene:
     def setBVHLeafTarget(self, target, tol=5): lib.hs_set_bvh_leaf_target(self._h, target, tol)
     def setMaxBounceDepth(self, d): lib.hs_set_max_bounce_depth(self._h, d)
     def setSamplesPerPixel(self, n): lib.hs_set_samples_per_pixel(self._h, n)
-    def setDenoiserEnabled(self, e): lib.hs_set_denoiser_enabled(self._h, int(e))
+    def setDenoiserEnabled(self, e): self._chk(lib.hs_set_denoiser_enabled(self._h, int(e)))
     def setBloomEnabled(self, e): lib.hs_set_bloom_enabled(self._h, int(e))
-    def setPerformancePreset(self, name): lib.hs_set_performance_preset(self._h, name.encode())
+    def setPerformancePreset(self, name): self._chk(lib.hs_set_performance_preset(self._h, name.encode()))
+    def setResolutionScale(self, s): self._chk(lib.hs_set_resolution_scale(self._h, float(s)))
+
+    def renderSize(self):
+        """(render_width, render_height): the size the path tracer runs at (perfSettings.resolutionScale)."""
+        w, h = C.c_int(), C.c_int()
+        lib.hs_get_render_size(self._h, C.byref(w), C.byref(h))
+        return w.value, h.value
     def setMeshMaterial(self, mesh, mat): self._chk(lib.hs_set_mesh_material(self._h, mesh, mat.ptr()))
 
     def settings(self):
@@ -411,10 +422,12 @@ class Scene:
 
     def read(self, kind):
         n = self.tile_rows * self.width
-        shape, dt = {BUF_ACCUM: ((n, 3), np.float32), BUF_NORMAL: ((n, 3), np.float32), BUF_DEPTH: ((n,), np.float32),
-                     BUF_OBJECT_ID: ((n,), np.int32), BUF_RGB8: ((self.tile_rows, self.width, 3), np.uint8),
-                     BUF_RNG: ((n, 6), np.uint32), BUF_DENOISED: ((n, 3), np.float32),
-                     BUF_MOTION: ((n, 2), np.float32)}[kind]
+        rw, rh = self.renderSize()
+        r = n if (rw, rh) == (self.width, self.height) else rw * rh   # render-size images (see ptrt.h)
+        shape, dt = {BUF_ACCUM: ((n, 3), np.float32), BUF_NORMAL: ((r, 3), np.float32), BUF_DEPTH: ((r,), np.float32),
+                     BUF_OBJECT_ID: ((r,), np.int32), BUF_RGB8: ((self.tile_rows, self.width, 3), np.uint8),
+                     BUF_RNG: ((n, 6), np.uint32), BUF_DENOISED: ((r, 3), np.float32),
+                     BUF_MOTION: ((r, 2), np.float32), BUF_RENDER_ACCUM: ((r, 3), np.float32)}[kind]
         out = np.empty(shape, dtype=dt)
         self._cchk(lib.ptrt_read_buffer(self.ctx, kind, out.ctypes.data_as(_vp), out.nbytes))
         return out

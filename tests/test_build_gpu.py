@@ -104,6 +104,7 @@ def test_radix_sort_at_scale_and_rebuild_from_device(P, O, blue_noise):
     s.setSamplesPerPixel(1)
     s.setMaxBounceDepth(3)
     s.setDenoiserEnabled(False)
+    s.setBloomEnabled(False)
     s.initBlueNoise()
     s.uploadToGPU()
     v = P.scenes.water_vertices(256, 0.9)

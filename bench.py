@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--denoise", action="store_true",
                     help="also run motion vectors + the spatiotemporal denoiser each frame (N=1 only; not the headline)")
+    ap.add_argument("--bloom", action="store_true", help="also run the bloom chain (N=1 only; not the headline)")
+    ap.add_argument("--scale", type=float, default=1.0,
+                    help="perfSettings.resolutionScale: trace at scale*size, bilinear up-scale (N=1 only; not the headline)")
     ap.add_argument("--rebuild", action="store_true",
                     help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
     args = ap.parse_args()
@@ -102,8 +105,10 @@ def main():
     scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, local_rank)
     scene.setSamplesPerPixel(args.spp)
     scene.setMaxBounceDepth(args.depth)
-    if args.denoise and world == 1:
-        scene.setDenoiserEnabled(True)
+    if world == 1:
+        scene.setDenoiserEnabled(args.denoise)
+        scene.setBloomEnabled(args.bloom)
+        scene.setResolutionScale(args.scale)
     scene.initBlueNoise()
     scene.uploadToGPU()
     scene.set_option("count_rays", 1)
@@ -198,7 +203,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "fps": round(fps, 2),
         "rays_per_frame": round(rays / args.steps),
-        "config": {"workload": f"{args.scene} {W}x{H} {args.spp}spp {args.depth}-bounce", "scene": args.scene,
+        "config": {"workload": f"{args.scene} {W}x{H} {args.spp}spp {args.depth}-bounce"
+                               + (" +denoise" if args.denoise else "") + (" +bloom" if args.bloom else "")
+                               + (f" scale{args.scale}" if args.scale != 1.0 else "")
+                               + (" +gpu-rebuild" if args.rebuild else ""), "scene": args.scene,
                    "width": W, "height": H, "spp": args.spp, "max_depth": args.depth,
                    "parallelism": f"tile{world}" if world > 1 else "single",
                    "kernel": "path_trace_kernel (megakernel, fused tonemap)"},

@@ -320,20 +320,64 @@ __global__ __launch_bounds__(256) void variance_kernel(float4 *__restrict__ out_
 }
 
 // ------------------------------------------------------------------ a-trous wavelet pass on C4
+// A pass with step s combines a pixel only with pixels of its own row class (y mod s), so a
+// workgroup takes 64 CONSECUTIVE pixels of 4 rows of one class: the footprint of its 25 taps is
+// 8 rows (the class's neighbours) x (64 + 4s) consecutive pixels, staged in LDS once with
+// coalesced dwordx4 loads (<= 36 KB at s = 16: {rgb,var} + {normal,depth} + object id per entry)
+// and read back with ds_read_b128, instead of being gathered 25 times through a 32-KB L1 that
+// eight resident workgroups thrash (first cut: 74 % of wave-cycles in s_waitcnt, FETCH_SIZE 2.9x
+// the image).  Tiling BOTH axes by class (16x16 pixels of one (x mod s, y mod s)) staged less
+// but made every global access a lone 16-B piece of its sector: faster for s <= 4, slower for
+// s >= 8 (133 / 156 us) -- rows by class, columns contiguous is coalesced for every s.
 // LAST: also writes the API's vec3 image and the tonemapped RGB8 (rows flipped), saving two passes.
+constexpr int AT_W = 64, AT_ROWS = 4;
+constexpr int AT_OUTSIDE = (int)0x80000000; // object-id slot of a footprint entry that lies outside the image
+PT_DEV int atrous_span(int step) { return AT_W + 4 * step; }
+inline size_t atrous_lds_bytes(int step) { return (size_t)(AT_W + 4 * step) * (AT_ROWS + 4) * 36; }
 template <bool LAST>
 __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4, const float4 *__restrict__ in_c4,
                                                      const float4 *__restrict__ g4, const int *__restrict__ object_id,
                                                      int step, float sigma_lum, float sky, float edt, float ent, int use_obj_i,
                                                      int W, int H, float *__restrict__ out3, unsigned char *__restrict__ rgb8) {
-    PT_PIXEL_XY
+    extern __shared__ float4 at_lds[];
     constexpr float KW[5] = {1.0f, 4.0f, 6.0f, 4.0f, 1.0f};
     const bool uo = use_obj_i != 0;
-    const float4 c4 = in_c4[idx];
-    const float4 g = g4[idx];
+    const int span = atrous_span(step), entries = span * (AT_ROWS + 4);
+    float4 *s_c = at_lds, *s_g = at_lds + entries;
+    int *s_o = reinterpret_cast<int *>(at_lds + 2 * entries);
+    const int x0 = blockIdx.x * AT_W, ry = blockIdx.y % step, tyd = blockIdx.y / step;
+    {   // threads 0..127 stage footprint row 2k, threads 128..255 row 2k+1 (span <= 128 for step <= 16)
+        const int ex = threadIdx.x & 127;
+        const int px = x0 - 2 * step + ex;
+        for (int k = 0; k < (AT_ROWS + 4) / 2; ++k) {
+            const int ey = 2 * k + (threadIdx.x >> 7);
+            const int yd = tyd * AT_ROWS - 2 + ey; // row index within the class
+            const int py = yd * step + ry;
+            if (ex < span) {
+                const int e = ey * span + ex;
+                if (px >= 0 && px < W && yd >= 0 && py < H) {
+                    const int pi = py * W + px;
+                    s_c[e] = in_c4[pi];
+                    s_g[e] = g4[pi];
+                    s_o[e] = uo ? object_id[pi] : 0;
+                } else {
+                    s_o[e] = AT_OUTSIDE;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ti = threadIdx.x & (AT_W - 1), tj = threadIdx.x >> 6;
+    const int x = x0 + ti, y = (tyd * AT_ROWS + tj) * step + ry;
+    if (x >= W || y >= H)
+        return;
+    const int idx = y * W + x;
+    const int ce = (tj + 2) * span + 2 * step + ti;
+    const float4 c4 = s_c[ce];
+    const float4 g = s_g[ce];
     const f3 cc = xyz(c4), cn = xyz(g);
     const float cd = g.w, cvar = c4.w;
-    const int cobj = uo ? object_id[idx] : -1;
+    const int cobj = uo ? s_o[ce] : -1;
     const float clum = luminance(cc);
     f3 res = cc;
     float res_var = cvar;
@@ -345,16 +389,13 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
         float sum_var = 0.0f, total_w = 0.0f;
         for (int dy = -2; dy <= 2; ++dy)
             for (int dx = -2; dx <= 2; ++dx) {
-                const int nx = x + dx * step, ny = y + dy * step;
-                if (nx < 0 || nx >= W || ny < 0 || ny >= H)
+                const int ne = ce + dy * span + dx * step; // (x + dx*step, y + dy*step)
+                const int nobj = s_o[ne];
+                if (nobj == AT_OUTSIDE) // nx < 0 || nx >= W || ny < 0 || ny >= H
                     continue;
-                const int ni = ny * W + nx;
-                if (uo) {
-                    const int nobj = object_id[ni];
-                    if (cobj != nobj && cobj >= 0 && nobj >= 0)
-                        continue;
-                }
-                const float4 ng = g4[ni];
+                if (uo && cobj != nobj && cobj >= 0 && nobj >= 0)
+                    continue;
+                const float4 ng = s_g[ne];
                 const float max_d = max_(cd, ng.w);
                 const float dd = __builtin_fabsf(cd - ng.w);
                 if (max_d > 1e-6f && dd / max_d > edt)
@@ -364,7 +405,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                     continue;
                 if (is_sky(ng.w, nn, sky))
                     continue;
-                const float4 nc4 = in_c4[ni];
+                const float4 nc4 = s_c[ne];
                 const f3 nc = xyz(nc4);
                 const float ld = __builtin_fabsf(clum - luminance(nc));
                 const float wl = det_exp(-ld * ld * inv_sl2);

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTRT_ABI_VERSION 1
+#define PTRT_ABI_VERSION 2 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height */
 
 enum {
     PTRT_OK = 0,
@@ -131,6 +131,11 @@ typedef struct ptrt_scene_desc {
     ptrt_camera camera;
     ptrt_vec3 sky_top, sky_bottom;
     int32_t use_sky;
+    /* Scene::loadHDRI's equirectangular map (scene.cuh:959-1026): env_width*env_height RGBA
+     * floats, row 0 = what stbi_loadf returns first with flip_vertically_on_load(true);
+     * NULL = none (`d_env_texture == 0`: the sky is the gradient).  ABI version 2. */
+    const float *env_rgba;
+    int32_t env_width, env_height;
 } ptrt_scene_desc;
 
 /* HitInfo, math/intersection.cuh:108-124, as returned by Scene::traceSingleRay. */
@@ -215,6 +220,15 @@ int ptrt_set_camera(ptrt_ctx *ctx, const ptrt_camera *cam);
 
 /* Scene::setSkyGradient / disableSky (scene.cuh:1548-1565). */
 int ptrt_set_sky(ptrt_ctx *ctx, const ptrt_vec3 *top, const ptrt_vec3 *bottom, int use_sky);
+
+/* Scene::loadHDRI's device side (scene.cuh:976-1022): the equirectangular environment map that
+ * sampleSky reads with tex2D<float4>(envMap, u, v) (render_utils.cuh:115-137) -- normalised
+ * coordinates, address mode wrap in u / clamp in v, linear filtering.  `rgba`: width*height*4
+ * floats (host pointer, copied); NULL frees the map (freeHDRI) and the sky is the gradient
+ * again.  MI355X has no texture-filtering path worth a detour for one fetch per escaped ray: the
+ * bilinear fetch is restated in the kernel with the CUDA texture unit's documented arithmetic
+ * (xB = u*W - 0.5, weights quantised to 8 fractional bits).  SURVEY 8(f) rank 4. */
+int ptrt_set_env_map(ptrt_ctx *ctx, const float *rgba, int width, int height);
 
 /* Dynamic geometry, same topology (the `Triangles` path of updatePTScene,
  * src/common/PTRTtransfer.cuh:2249-2270, followed by Scene::commitObjectChanges,

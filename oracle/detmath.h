@@ -151,4 +151,68 @@ static inline float dm_log(float x) {
 /* x^y for x > 0 (the only use on the path: the sRGB OETF, x in (0.003,1]) */
 static inline float dm_pow(float x, float y) { return dm_exp(y * dm_log(x)); }
 
+/* atan for x >= 0 (Cephes atanf: two range reductions, degree-4 polynomial in x^2) */
+static inline float dm_atan_pos(float x) {
+    float y = 0.0f;
+    if (x > 0x1.3504f4p+1f) { /* tan(3 pi/8) */
+        y = 0x1.921fb6p+0f;   /* pi/2 */
+        x = -(1.0f / x);
+    } else if (x > 0x1.a8279ap-2f) { /* tan(pi/8) */
+        y = 0x1.921fb6p-1f;          /* pi/4 */
+        x = (x - 1.0f) / (x + 1.0f);
+    }
+    const float z = x * x;
+    float p = dm_fma(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = dm_fma(p, z, 1.99777106478e-1f);
+    p = dm_fma(p, z, -3.33329491539e-1f);
+    return y + dm_fma(p * z, x, x);
+}
+/* atan2f(y, x) in [-pi, pi] (sampleSky's phi, rendering/render_utils.cuh:126); NaN in -> NaN out */
+static inline float dm_atan2(float y, float x) {
+    if (x != x || y != y)
+        return x + y;
+    const float PI_F = 0x1.921fb6p+1f, PIO2_F = 0x1.921fb6p+0f;
+    if (x == 0.0f) {
+        if (y == 0.0f)
+            return (dm_bits(x) >> 31) ? ((dm_bits(y) >> 31) ? -PI_F : PI_F) : y;
+        return y < 0.0f ? -PIO2_F : PIO2_F;
+    }
+    if (y == 0.0f)
+        return x < 0.0f ? ((dm_bits(y) >> 31) ? -PI_F : PI_F) : y;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a; /* atan(|y|/|x|) in [0, pi/2] */
+    if (ax == INFINITY)
+        a = (ay == INFINITY) ? 0x1.921fb6p-1f : 0.0f;
+    else if (ay == INFINITY)
+        a = PIO2_F;
+    else
+        a = dm_atan_pos(ay / ax);
+    if (x < 0.0f)
+        a = PI_F - a;
+    return y < 0.0f ? -a : a;
+}
+/* acosf(x), |x| <= 1 (sampleSky's theta, render_utils.cuh:128; the argument is clamped there).
+ * Cephes asinf: x or sqrt((1-|x|)/2) into a degree-4 polynomial in its square. */
+static inline float dm_asin_core(float a, float z) { /* a + a*z*P(z) */
+    float p = dm_fma(4.2163199048e-2f, z, 2.4181311049e-2f);
+    p = dm_fma(p, z, 4.5470025998e-2f);
+    p = dm_fma(p, z, 7.4953002686e-2f);
+    p = dm_fma(p, z, 1.6666752422e-1f);
+    return dm_fma(p * z, a, a);
+}
+static inline float dm_acos(float x) {
+    if (!(fabsf(x) <= 1.0f))
+        return NAN;
+    const float PI_F = 0x1.921fb6p+1f, PIO2_F = 0x1.921fb6p+0f;
+    if (x > 0.5f) {
+        const float z = 0.5f * (1.0f - x);
+        return 2.0f * dm_asin_core(sqrtf(z), z);
+    }
+    if (x < -0.5f) {
+        const float z = 0.5f * (1.0f + x);
+        return PI_F - 2.0f * dm_asin_core(sqrtf(z), z);
+    }
+    return PIO2_F - dm_asin_core(x, x * x);
+}
+
 #endif

@@ -708,11 +708,51 @@ inline float attenuate(float distance, float range) { // render_utils.cuh:21-24
     float att = range / (range + distance);
     return att * att;
 }
-inline V3 sampleSky(const Ray &r, const V3 &top, const V3 &bottom, bool useSky) { // render_utils.cuh:115-125 (gradient only)
+// tex2D<float4>(envMap, u, v) for the texture object Scene::loadHDRI creates (scene.cuh:1007-1013:
+// normalizedCoords, addressMode wrap / clamp, cudaFilterModeLinear, element type), restated from the
+// CUDA C Programming Guide's "Texture Fetching" appendix: wrap takes frac(u); clamp takes v into
+// [0, 1 - 1/H]; xB = x*N - 0.5, i = floor(xB), alpha = frac(xB) kept in 1.8 fixed point (8
+// fractional bits; rounding to nearest is OUR choice, the guide does not say -- parity unpinned);
+// out-of-range texel indices follow the address mode; the four texels are blended in fp32.
+struct EnvMap {
+    const float *rgba;
+    int w, h;
+};
+inline V3 env_texel(const EnvMap &E, int i, int j) {
+    i %= E.w;
+    if (i < 0)
+        i += E.w;
+    j = j < 0 ? 0 : (j > E.h - 1 ? E.h - 1 : j);
+    const float *p = E.rgba + ((size_t)j * E.w + i) * 4;
+    return V3(p[0], p[1], p[2]);
+}
+inline V3 tex2D_env(const EnvMap &E, float u, float v) {
+    const float uw = u - floorf(u);
+    const float vmax = 1.0f - 1.0f / (float)E.h;
+    const float vc = v < 0.0f ? 0.0f : (v >= 1.0f ? vmax : v);
+    const float xB = uw * (float)E.w - 0.5f, yB = vc * (float)E.h - 0.5f;
+    const float fi = floorf(xB), fj = floorf(yB);
+    const float a = rintf((xB - fi) * 256.0f) * (1.0f / 256.0f), b = rintf((yB - fj) * 256.0f) * (1.0f / 256.0f);
+    const int i = (int)fi, j = (int)fj;
+    const V3 t00 = env_texel(E, i, j), t10 = env_texel(E, i + 1, j), t01 = env_texel(E, i, j + 1),
+             t11 = env_texel(E, i + 1, j + 1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return ((t00 * w00 + t10 * w10) + t01 * w01) + t11 * w11;
+}
+
+inline V3 sampleSky(const Ray &r, const V3 &top, const V3 &bottom, bool useSky, const EnvMap &env) { // render_utils.cuh:115-137
     if (!useSky)
         return V3(0.0f);
-    float t = 0.5f * (r.dir.y + 1.0f);
-    return lerp(bottom, top, t);
+    if (!env.rgba) {
+        float t = 0.5f * (r.dir.y + 1.0f);
+        return lerp(bottom, top, t);
+    }
+    const V3 dir = r.dir;
+    float phi = dm_atan2(dir.z, dir.x);
+    float theta = dm_acos(dm_max(-1.0f, dm_min(1.0f, dir.y)));
+    float u = (phi + PI_F) * (1.0f / TWO_PI_F);
+    float v = theta * (1.0f / PI_F);
+    return tex2D_env(env, u, v);
 }
 
 // ---------------------------------------------------------------------------
@@ -1234,7 +1274,7 @@ V3 tracePath(Ray ray, const ptrt_scene_desc &S, Xorwow &rng, int max_depth, V3 &
             }
         }
         if (!hit.hit) {
-            V3 sky = sampleSky(ray, skyTop, skyBottom, S.use_sky != 0);
+            V3 sky = sampleSky(ray, skyTop, skyBottom, S.use_sky != 0, EnvMap{S.env_rgba, S.env_width, S.env_height});
             accumulated_color = accumulated_color + throughput * sky;
             break;
         }
@@ -1617,6 +1657,8 @@ void oracle_detmath(int op, const float *x, const float *y, int n, float *out) {
         case 1: out[i] = dm_cos(x[i]); break;
         case 2: out[i] = dm_exp(x[i]); break;
         case 3: out[i] = dm_log(x[i]); break;
+        case 5: out[i] = dm_atan2(x[i], y[i]); break;
+        case 6: out[i] = dm_acos(x[i]); break;
         default: out[i] = dm_pow(x[i], y[i]); break;
         }
     }

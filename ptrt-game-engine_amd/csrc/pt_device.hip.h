@@ -186,6 +186,96 @@ PT_DEV float det_log(float x) {
 }
 PT_DEV float det_pow(float x, float y) { return det_exp(y * det_log(x)); }
 
+// atan for x >= 0 (Cephes atanf), atan2f and acosf for sampleSky's equirect lookup
+// (rendering/render_utils.cuh:126-128); same algorithms as oracle/detmath.h
+PT_DEV float det_atan_pos(float x) {
+    float y = 0.0f;
+    if (x > 0x1.3504f4p+1f) { // tan(3 pi/8)
+        y = 0x1.921fb6p+0f;
+        x = -(1.0f / x);
+    } else if (x > 0x1.a8279ap-2f) { // tan(pi/8)
+        y = 0x1.921fb6p-1f;
+        x = (x - 1.0f) / (x + 1.0f);
+    }
+    const float z = x * x;
+    float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fma_(p, z, 1.99777106478e-1f);
+    p = fma_(p, z, -3.33329491539e-1f);
+    return y + fma_(p * z, x, x);
+}
+PT_DEV float det_atan2(float y, float x) {
+    if (x != x || y != y)
+        return x + y;
+    const float PI_F = 0x1.921fb6p+1f, PIO2_F = 0x1.921fb6p+0f;
+    if (x == 0.0f) {
+        if (y == 0.0f)
+            return (__float_as_uint(x) >> 31) ? ((__float_as_uint(y) >> 31) ? -PI_F : PI_F) : y;
+        return y < 0.0f ? -PIO2_F : PIO2_F;
+    }
+    if (y == 0.0f)
+        return x < 0.0f ? ((__float_as_uint(y) >> 31) ? -PI_F : PI_F) : y;
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float INF = __builtin_inff();
+    float a;
+    if (ax == INF)
+        a = (ay == INF) ? 0x1.921fb6p-1f : 0.0f;
+    else if (ay == INF)
+        a = PIO2_F;
+    else
+        a = det_atan_pos(ay / ax);
+    if (x < 0.0f)
+        a = PI_F - a;
+    return y < 0.0f ? -a : a;
+}
+PT_DEV float det_asin_core(float a, float z) {
+    float p = fma_(4.2163199048e-2f, z, 2.4181311049e-2f);
+    p = fma_(p, z, 4.5470025998e-2f);
+    p = fma_(p, z, 7.4953002686e-2f);
+    p = fma_(p, z, 1.6666752422e-1f);
+    return fma_(p * z, a, a);
+}
+PT_DEV float det_acos(float x) {
+    if (!(__builtin_fabsf(x) <= 1.0f))
+        return __builtin_nanf("");
+    const float PI_F = 0x1.921fb6p+1f, PIO2_F = 0x1.921fb6p+0f;
+    if (x > 0.5f) {
+        const float z = 0.5f * (1.0f - x);
+        return 2.0f * det_asin_core(__builtin_sqrtf(z), z);
+    }
+    if (x < -0.5f) {
+        const float z = 0.5f * (1.0f + x);
+        return PI_F - 2.0f * det_asin_core(__builtin_sqrtf(z), z);
+    }
+    return PIO2_F - det_asin_core(x, x * x);
+}
+
+// tex2D<float4>(envMap, u, v) of the texture object Scene::loadHDRI creates (scene.cuh:1007-1013:
+// normalised coordinates, wrap in u / clamp in v, linear filter), restated from the CUDA C
+// Programming Guide's texture-fetching appendix: xB = frac(u)*W - 0.5, i = floor(xB), the weight
+// frac(xB) kept with 8 fractional bits; texel indices outside the map follow the address mode.
+PT_DEV f3 env_texel(const float4 *env, int w, int h, int i, int j) {
+    i %= w;
+    if (i < 0)
+        i += w;
+    j = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
+    const float4 t = env[(size_t)j * w + i];
+    return f3{t.x, t.y, t.z};
+}
+PT_DEV f3 tex2d_env(const float4 *env, int w, int h, float u, float v) {
+    const float uw = u - __builtin_floorf(u);
+    const float vmax = 1.0f - 1.0f / (float)h;
+    const float vc = v < 0.0f ? 0.0f : (v >= 1.0f ? vmax : v);
+    const float xB = uw * (float)w - 0.5f, yB = vc * (float)h - 0.5f;
+    const float fi = __builtin_floorf(xB), fj = __builtin_floorf(yB);
+    const float a = __builtin_rintf((xB - fi) * 256.0f) * (1.0f / 256.0f),
+                b = __builtin_rintf((yB - fj) * 256.0f) * (1.0f / 256.0f);
+    const int i = (int)fi, j = (int)fj;
+    const f3 t00 = env_texel(env, w, h, i, j), t10 = env_texel(env, w, h, i + 1, j), t01 = env_texel(env, w, h, i, j + 1),
+             t11 = env_texel(env, w, h, i + 1, j + 1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return ((t00 * w00 + t10 * w10) + t01 * w01) + t11 * w11;
+}
+
 // ------------------------------------------------------------------ XORWOW
 struct Rng {
     uint32_t d, v0, v1, v2, v3, v4;

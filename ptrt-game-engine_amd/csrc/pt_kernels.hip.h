@@ -74,6 +74,8 @@ struct KParams {
     Camera cam;
     f3 sky_top, sky_bottom;
     int use_sky;
+    const float4 *env; // equirectangular environment map (Scene::loadHDRI) or NULL
+    int env_w, env_h;
     int width, height; // full frame
     int y0, rows;      // tile
     int tiles_x;
@@ -1004,6 +1006,8 @@ __global__ void detmath_kernel(int op, const float *x, const float *y, int n, fl
     case 1: r = det_cos(x[i]); break;
     case 2: r = det_exp(x[i]); break;
     case 3: r = det_log(x[i]); break;
+    case 5: r = det_atan2(x[i], y[i]); break;
+    case 6: r = det_acos(x[i]); break;
     default: r = det_pow(x[i], y[i]); break;
     }
     out[i] = r;

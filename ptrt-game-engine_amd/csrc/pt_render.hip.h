@@ -436,9 +436,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
                     K.depth[idx] = 1e30f;
                     K.object_id[idx] = -1;
                 }
-                if (K.use_sky) { // sampleSky, gradient (render_utils.cuh:115-125)
-                    const float t = 0.5f * (rd.y + 1.0f);
-                    acc = acc + throughput * lerp(K.sky_bottom, K.sky_top, t);
+                if (K.use_sky) { // sampleSky (render_utils.cuh:115-137): gradient, or the equirect map
+                    if (K.env) {
+                        const float phi = det_atan2(rd.z, rd.x);
+                        const float theta = det_acos(max_(-1.0f, min_(1.0f, rd.y)));
+                        const float u = (phi + PI_F) * (1.0f / TWO_PI_F);
+                        const float v = theta * (1.0f / PI_F);
+                        acc = acc + throughput * tex2d_env(K.env, K.env_w, K.env_h, u, v);
+                    } else {
+                        const float t = 0.5f * (rd.y + 1.0f);
+                        acc = acc + throughput * lerp(K.sky_bottom, K.sky_top, t);
+                    }
                 } else {
                     acc = acc + throughput * mk3(0.0f);
                 }

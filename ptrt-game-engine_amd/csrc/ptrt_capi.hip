@@ -94,6 +94,8 @@ struct ptrt_ctx {
     pt::Camera cam{};
     pt::f3 sky_top{0.6f, 0.7f, 1.0f}, sky_bottom{1.0f, 1.0f, 1.0f};
     int use_sky = 1;
+    float4 *d_env = nullptr; // equirectangular environment map (ptrt_set_env_map)
+    int env_w = 0, env_h = 0;
 
     // denoiser (class Denoiser, denoiser.cuh:781-1070): scratch + double-buffered history
     bool dn_on = false, dn_first = true;
@@ -377,6 +379,9 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.sky_top = c->sky_top;
     K.sky_bottom = c->sky_bottom;
     K.use_sky = c->use_sky;
+    K.env = c->d_env;
+    K.env_w = c->env_w;
+    K.env_h = c->env_h;
     // at a reduced render size (full-frame contexts only) the frame is rw x rh in the d_scaled_* set; the
     // generator states stay where they are: pixel p of the small frame uses state p (scene.cuh:1091-1098)
     const bool scaled = c->scaled();
@@ -754,6 +759,7 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_counters);
     dfree(c->d_blue);
     dfree(c->d_jump);
+    dfree(c->d_env);
     free_denoiser(c);
     free_post(c);
     for (auto &ev : c->ev_ring)
@@ -1244,7 +1250,30 @@ int ptrt_upload_scene(ptrt_ctx *c, const ptrt_scene_desc *s) {
         return rc;
     if (int rc = ptrt_set_camera(c, &s->camera))
         return rc;
+    if (int rc = ptrt_set_env_map(c, s->env_rgba, s->env_width, s->env_height))
+        return rc;
     return ptrt_set_sky(c, &s->sky_top, &s->sky_bottom, s->use_sky);
+}
+
+int ptrt_set_env_map(ptrt_ctx *c, const float *rgba, int width, int height) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_set_env_map: bad context");
+    if (rgba && (width < 1 || height < 1))
+        return fail(c, PTRT_E_INVALID, "ptrt_set_env_map: %dx%d is not a map size", width, height);
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // frames in flight may still read the old map
+    dfree(c->d_env);
+    c->env_w = c->env_h = 0;
+    if (!rgba)
+        return PTRT_OK;
+    const size_t bytes = (size_t)width * height * 16;
+    HIP_TRY(c, hipMalloc((void **)&c->d_env, bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->d_env, rgba, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->env_w = width;
+    c->env_h = height;
+    return PTRT_OK;
 }
 
 void ptrt_denoiser_default_settings(ptrt_denoiser_settings *s) {

@@ -196,6 +196,12 @@ void hs_set_sky_gradient(void *s, const float *top3, const float *bottom3) {
     static_cast<Scene *>(s)->setSkyGradient(vec3(top3[0], top3[1], top3[2]), vec3(bottom3[0], bottom3[1], bottom3[2]));
 }
 void hs_disable_sky(void *s) { static_cast<Scene *>(s)->disableSky(); }
+int hs_load_hdri(void *s, const char *path) { HS_TRY(static_cast<Scene *>(s)->loadHDRI(path)); return 0; }
+int hs_set_environment_map(void *s, const float *rgba, int w, int h) {
+    HS_TRY(static_cast<Scene *>(s)->setEnvironmentMap(rgba, w, h));
+    return 0;
+}
+void hs_free_hdri(void *s) { static_cast<Scene *>(s)->freeHDRI(); }
 
 void hs_set_bvh_leaf_target(void *s, int target, int tol) { static_cast<Scene *>(s)->setBVHLeafTarget(target, tol); }
 void hs_set_max_bounce_depth(void *s, int d) { static_cast<Scene *>(s)->setMaxBounceDepth(d); }

@@ -9,6 +9,7 @@
 // debug-visualisation helpers -- their setters are accepted and recorded so call
 // sites compile, and `render_to_device` reports when one is enabled.
 #pragma once
+#include "hdr.hpp"
 #include "mesh.hpp"
 
 #include <cstdint>
@@ -416,6 +417,33 @@ class Scene {
         resetAccumulation();
     }
     void disableSky() { use_sky = false; skyDirty = true; resetAccumulation(); }
+    // scene.cuh:958-1026: an equirectangular .hdr picture becomes the sky (stbi_loadf, 4 channels,
+    // flipped vertically -> host/ptrt/hdr.hpp reads the same floats); sampleSky then looks it up
+    // instead of the gradient.  setEnvironmentMap is the same without the file.
+    void loadHDRI(const std::string &filepath) {
+        std::cout << "Loading HDRI: " << filepath << "..." << std::endl;
+        std::vector<float> rgba;
+        int w = 0, h = 0;
+        ptrt_detail::load_radiance_hdr(filepath, w, h, rgba);
+        std::cout << "Loaded HDRI: " << w << "x" << h << std::endl;
+        setEnvironmentMap(rgba.data(), w, h);
+    }
+    void setEnvironmentMap(const float *rgba, int w, int h) {
+        if (!rgba || w < 1 || h < 1)
+            throw std::runtime_error("setEnvironmentMap: empty map");
+        envMap.assign(rgba, rgba + (size_t)w * h * 4);
+        env_width = w;
+        env_height = h;
+        envDirty = true;
+        use_sky = true;
+        skyDirty = true;
+        resetAccumulation();
+    }
+    void freeHDRI() { // scene.cuh:944-956
+        envMap.clear();
+        env_width = env_height = 0;
+        envDirty = true;
+    }
 
     // ---- materials / objects ---------------------------------------------------------
     void setMeshMaterial(size_t index, const Material &mat) {
@@ -672,6 +700,9 @@ class Scene {
     ptrt_ctx *ctx = nullptr;
     bool geometryDirty = true, materialsDirty = true, lightsDirty = true, cameraDirty = true, skyDirty = true;
     bool warnedPost = false, denoiserAllocated = false;
+    std::vector<float> envMap;                // RGBA floats of the HDRI sky (empty: gradient)
+    int env_width = 0, env_height = 0;
+    bool envDirty = false;
     bool fullFrame = false;                   // band (tile) contexts have no post chain
     int render_width = 0, render_height = 0;  // scene.cuh:203-204
     mat4 prev_view_proj; // proj*view of the previous frame (scene.cuh:113)
@@ -857,6 +888,9 @@ class Scene {
         flat.sky_top = c(sky_color_top);
         flat.sky_bottom = c(sky_color_bottom);
         flat.use_sky = use_sky ? 1 : 0;
+        flat.env_rgba = envMap.empty() ? nullptr : envMap.data();
+        flat.env_width = env_width;
+        flat.env_height = env_height;
     }
 
     void updateAccelerationStructures() {
@@ -921,6 +955,11 @@ class Scene {
                 b{sky_color_bottom.x, sky_color_bottom.y, sky_color_bottom.z};
             check(ptrt_set_sky(ctx, &t, &b, use_sky ? 1 : 0), "Failed to set sky");
             skyDirty = false;
+        }
+        if (envDirty) {
+            check(ptrt_set_env_map(ctx, envMap.empty() ? nullptr : envMap.data(), env_width, env_height),
+                  "Failed to upload the environment map");
+            envDirty = false;
         }
         int rc = ptrt_render(ctx, frame_count_, perfSettings.samplesPerPixel, perfSettings.maxBounceDepth, pixels,
                              is_device);

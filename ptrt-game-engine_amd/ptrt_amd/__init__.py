@@ -82,7 +82,8 @@ class SceneDesc(C.Structure):
                 ("tlas_mesh_indices", C.POINTER(C.c_int32)), ("tlas_index_count", C.c_int32),
                 ("materials", Materials),
                 ("lights", C.POINTER(Light)), ("light_count", C.c_int32),
-                ("camera", Camera), ("sky_top", Vec3), ("sky_bottom", Vec3), ("use_sky", C.c_int32)]
+                ("camera", Camera), ("sky_top", Vec3), ("sky_bottom", Vec3), ("use_sky", C.c_int32),
+                ("env_rgba", C.POINTER(C.c_float)), ("env_width", C.c_int32), ("env_height", C.c_int32)]
 
 
 class Hit(C.Structure):
@@ -166,6 +167,10 @@ _sig("hs_move_camera", None, _vp, _fp)
 _sig("hs_look_camera_at", None, _vp, _fp)
 _sig("hs_set_sky_gradient", None, _vp, _fp, _fp)
 _sig("hs_disable_sky", None, _vp)
+_sig("hs_load_hdri", C.c_int, _vp, C.c_char_p)
+_sig("hs_set_environment_map", C.c_int, _vp, _fp, C.c_int, C.c_int)
+_sig("hs_free_hdri", None, _vp)
+_sig("ptrt_set_env_map", C.c_int, _vp, _fp, C.c_int, C.c_int)
 _sig("hs_set_bvh_leaf_target", None, _vp, C.c_int, C.c_int)
 _sig("hs_set_max_bounce_depth", None, _vp, C.c_int)
 _sig("hs_set_samples_per_pixel", None, _vp, C.c_int)
@@ -342,6 +347,14 @@ class Scene:
     def lookCameraAt(self, at): lib.hs_look_camera_at(self._h, _f3(at))
     def setSkyGradient(self, top, bottom): lib.hs_set_sky_gradient(self._h, _f3(top), _f3(bottom))
     def disableSky(self): lib.hs_disable_sky(self._h)
+    def loadHDRI(self, path): self._chk(lib.hs_load_hdri(self._h, str(path).encode()))
+    def freeHDRI(self): lib.hs_free_hdri(self._h)
+
+    def setEnvironmentMap(self, rgba):
+        """(h, w, 4) float32 equirectangular map, row 0 = v 0 (what loadHDRI would hand over)."""
+        a = np.ascontiguousarray(rgba, dtype=np.float32)
+        assert a.ndim == 3 and a.shape[2] == 4
+        self._chk(lib.hs_set_environment_map(self._h, _fptr(a), a.shape[1], a.shape[0]))
 
     # settings
     def setBVHLeafTarget(self, target, tol=5): lib.hs_set_bvh_leaf_target(self._h, target, tol)

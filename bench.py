@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--bloom", action="store_true", help="also run the bloom chain (N=1 only; not the headline)")
     ap.add_argument("--scale", type=float, default=1.0,
                     help="perfSettings.resolutionScale: trace at scale*size, bilinear up-scale (N=1 only; not the headline)")
+    ap.add_argument("--present", type=int, default=0, metavar="SLOTS",
+                    help="N=1 only, not the headline: after the timed loop also run the viewer loop (device frame -> pinned "
+                         "host, SLOTS-deep ring) and report its PCIe-inclusive ms/frame as config.present_ms_per_frame")
     ap.add_argument("--rebuild", action="store_true",
                     help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
     args = ap.parse_args()
@@ -217,6 +220,12 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "path is VALU/latency bound, not HBM bound (SURVEY 8(d)); see DESIGN.md"},
     }
+    if args.present > 0 and world == 1:
+        scene.set_stream(0)  # the viewer loop runs on the context's own stream
+        scene.view_run(args.warmup + 2, slots=args.present, keep=False)
+        _, pms = scene.view_run(args.steps, slots=args.present, keep=False)
+        out["config"]["present_ms_per_frame"] = round(pms, 4)
+        out["config"]["present_slots"] = args.present
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(P, args.scene, W, H, args.spp, args.depth, 0,
                                            min(16, len(os.sched_getaffinity(0))))

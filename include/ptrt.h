@@ -309,6 +309,25 @@ int ptrt_set_bloom(ptrt_ctx *ctx, int enabled);
  * render_w = max(64, int(W * scale)) like the reference.  Full-frame contexts only. */
 int ptrt_set_render_size(ptrt_ctx *ctx, int render_w, int render_h);
 
+/* ---- presentation "next" row: the HIP half of rtgl::* ----
+ * The reference presents through a CUDA-mapped GL pixel-buffer object
+ * (src/common/glfw_view_interop.hpp:281-332: map_pbo_device_ptr -> render_to_device -> unmap_pbo
+ * -> blit_pbo_to_texture -> draw_interop).  MI355X has no GL interop, so the PBO becomes a ring of
+ * `slots` device RGB8 frames, each mirrored into PINNED host memory:
+ *   ptrt_present_map(slot)      = map_pbo_device_ptr: the device pointer to render into (first waits
+ *                                 until the slot's previous download has finished)
+ *   ptrt_present_unmap(slot)    = unmap_pbo: enqueues the asynchronous device->host copy of the frame
+ *                                 on the context's stream and records the slot's event; does not block
+ *   ptrt_present_acquire(slot)  = what blit_pbo_to_texture needs: waits for that event and returns the
+ *                                 pinned host pixels (W*H*3, bottom-up) for glTexSubImage2D / a file
+ * With slots >= 2 the copy of frame i overlaps the rendering of frame i+1 (the viewer maps slot
+ * (i+1)%slots while frame i is in flight).  Full-frame or band contexts alike. */
+int ptrt_present_create(ptrt_ctx *ctx, int slots);
+int ptrt_present_map(ptrt_ctx *ctx, int slot, void **device_pixels);
+int ptrt_present_unmap(ptrt_ctx *ctx, int slot);
+int ptrt_present_acquire(ptrt_ctx *ctx, int slot, const unsigned char **host_pixels);
+int ptrt_present_destroy(ptrt_ctx *ctx);
+
 /* convenience: the five uploads above from one flattened description */
 int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);
 

@@ -119,6 +119,15 @@ struct ptrt_ctx {
     bool scaled() const { return rw != W || rh != H; }
     size_t rpix() const { return scaled() ? (size_t)rw * rh : npix; } // pixels the path tracer renders
 
+    // presentation ring (ptrt_present_*): device RGB8 frames mirrored into pinned host memory
+    struct PresentSlot {
+        unsigned char *dev = nullptr, *host = nullptr;
+        hipEvent_t rendered = nullptr, done = nullptr;
+        bool in_flight = false;
+    };
+    std::vector<PresentSlot> present;
+    hipStream_t present_stream = nullptr;
+
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1;
     bool timed = false;
@@ -642,6 +651,25 @@ int run_bloom(ptrt_ctx *c, float *image, int w, int h, unsigned char *rgb8) {
     return PTRT_OK;
 }
 
+void free_present(ptrt_ctx *c) {
+    for (auto &s : c->present) {
+        if (s.dev)
+            (void)hipFree(s.dev);
+        if (s.host)
+            (void)hipHostFree(s.host);
+        if (s.rendered)
+            (void)hipEventDestroy(s.rendered);
+        if (s.done)
+            (void)hipEventDestroy(s.done);
+    }
+    c->present.clear();
+    if (c->present_stream) {
+        (void)hipStreamSynchronize(c->present_stream);
+        (void)hipStreamDestroy(c->present_stream);
+        c->present_stream = nullptr;
+    }
+}
+
 void free_post(ptrt_ctx *c) {
     dfree(c->s_accum);
     dfree(c->s_normal);
@@ -762,6 +790,7 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_env);
     free_denoiser(c);
     free_post(c);
+    free_present(c);
     for (auto &ev : c->ev_ring)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -1470,6 +1499,80 @@ int ptrt_sync(ptrt_ctx *c) {
     if (int rc = set_device(c))
         return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTRT_OK;
+}
+
+int ptrt_present_destroy(ptrt_ctx *c) {
+    if (!ctx_live(c))
+        return fail(c, PTRT_E_INVALID, "ptrt_present_destroy: bad context");
+    if (c->present.empty())
+        return PTRT_OK;
+    if (int rc = set_device(c))
+        return rc;
+    (void)hipStreamSynchronize(c->stream);
+    free_present(c);
+    return PTRT_OK;
+}
+
+int ptrt_present_create(ptrt_ctx *c, int slots) {
+    if (!ctx_live(c) || slots < 1 || slots > 8)
+        return fail(c, PTRT_E_INVALID, "ptrt_present_create: 1..8 slots");
+    if (int rc = ptrt_present_destroy(c))
+        return rc;
+    const size_t bytes = c->npix * 3;
+    c->present.resize((size_t)slots);
+    for (auto &s : c->present) {
+        HIP_TRY(c, hipMalloc((void **)&s.dev, bytes));
+        HIP_TRY(c, hipHostMalloc((void **)&s.host, bytes, hipHostMallocDefault));
+        HIP_TRY(c, hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    if (!c->present_stream)
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->present_stream, hipStreamNonBlocking));
+    return PTRT_OK;
+}
+
+int ptrt_present_map(ptrt_ctx *c, int slot, void **device_pixels) {
+    if (!ctx_live(c) || !device_pixels || slot < 0 || slot >= (int)c->present.size())
+        return fail(c, PTRT_E_INVALID, "ptrt_present_map: no such slot (ptrt_present_create first)");
+    if (int rc = set_device(c))
+        return rc;
+    auto &s = c->present[(size_t)slot];
+    if (s.in_flight) { // the frame about to be overwritten must have reached the host
+        HIP_TRY(c, hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    *device_pixels = s.dev;
+    return PTRT_OK;
+}
+
+int ptrt_present_unmap(ptrt_ctx *c, int slot) {
+    if (!ctx_live(c) || slot < 0 || slot >= (int)c->present.size())
+        return fail(c, PTRT_E_INVALID, "ptrt_present_unmap: no such slot");
+    if (int rc = set_device(c))
+        return rc;
+    auto &s = c->present[(size_t)slot];
+    // the download runs on its own stream behind an event, so it overlaps the NEXT frame's kernels
+    // (a copy enqueued on the render stream would only be asynchronous to the host)
+    HIP_TRY(c, hipEventRecord(s.rendered, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->present_stream, s.rendered, 0));
+    HIP_TRY(c, hipMemcpyAsync(s.host, s.dev, c->npix * 3, hipMemcpyDeviceToHost, c->present_stream));
+    HIP_TRY(c, hipEventRecord(s.done, c->present_stream));
+    s.in_flight = true;
+    return PTRT_OK;
+}
+
+int ptrt_present_acquire(ptrt_ctx *c, int slot, const unsigned char **host_pixels) {
+    if (!ctx_live(c) || !host_pixels || slot < 0 || slot >= (int)c->present.size())
+        return fail(c, PTRT_E_INVALID, "ptrt_present_acquire: no such slot");
+    if (int rc = set_device(c))
+        return rc;
+    auto &s = c->present[(size_t)slot];
+    if (s.in_flight) {
+        HIP_TRY(c, hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    *host_pixels = s.host;
     return PTRT_OK;
 }
 

@@ -3,7 +3,10 @@
 // callers can drive the same host API a C++ application uses.  One function per
 // Scene method; C++ exceptions become negative return codes + hs_last_error().
 #include "../host/ptrt/scene.hpp"
+#include "../host/ptrt/view.hpp"
 
+#include <chrono>
+#include <cstring>
 #include <string>
 
 namespace {
@@ -287,6 +290,49 @@ int hs_trace_single_ray(void *s, const float *o3, const float *d3, ptrt_hit *out
 int hs_save_ppm(void *s, const char *path, unsigned char *pixels) {
     HS_TRY(static_cast<Scene *>(s)->saveAsPPM(path, pixels));
     return 0;
+}
+
+// The reference's frame loop (readme.txt:100-119 / glfw_view_interop.hpp:281-332) over host/ptrt/view.hpp:
+// renders `frames` frames through the presentation ring; every presented frame is copied to
+// out_frames (frames * W*H*3 bytes, may be NULL) in presentation order; returns wall ms per frame
+// (PCIe-inclusive) in *ms_per_frame.  dump_prefix non-empty: every dump_every-th frame as PPM.
+int hs_view_run(void *s, int frames, int slots, unsigned char *out_frames, double *ms_per_frame, const char *dump_prefix,
+                int dump_every) {
+    try {
+        Scene &scene = *static_cast<Scene *>(s);
+        rtgl::InteropViewer V;
+        rtgl::init_interop_viewer(V, scene, "headless", slots);
+        V.dump_prefix = dump_prefix ? dump_prefix : "";
+        V.dump_every = dump_every;
+        const size_t bytes = scene.getPixelBufferSize();
+        size_t got = 0;
+        auto present = [&](bool flush) {
+            rtgl::blit_pbo_to_texture(V, flush);
+            if (V.host_frame) {
+                if (out_frames)
+                    std::memcpy(out_frames + got * bytes, V.host_frame, bytes);
+                ++got;
+                rtgl::draw_interop(V);
+            }
+        };
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < frames; ++f) {
+            uint8_t *d = rtgl::map_pbo_device_ptr(V);
+            scene.render_to_device(d);
+            rtgl::unmap_pbo(V);
+            present(false);
+        }
+        while (got < (size_t)frames)
+            present(true); // drain the ring
+        const auto t1 = std::chrono::steady_clock::now();
+        if (ms_per_frame)
+            *ms_per_frame = std::chrono::duration<double, std::milli>(t1 - t0).count() / (frames > 0 ? frames : 1);
+        rtgl::destroy_interop_viewer(V);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
 }
 
 // flattened scene (host pointers owned by the Scene, valid until it is mutated)

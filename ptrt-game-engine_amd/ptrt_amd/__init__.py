@@ -208,6 +208,12 @@ _sig("hs_get_frame_count", C.c_int, _vp)
 _sig("hs_set_frame_count", None, _vp, C.c_int)
 _sig("hs_trace_single_ray", C.c_int, _vp, _fp, _fp, C.POINTER(Hit))
 _sig("hs_save_ppm", C.c_int, _vp, C.c_char_p, _vp)
+_sig("hs_view_run", C.c_int, _vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_double), C.c_char_p, C.c_int)
+_sig("ptrt_present_create", C.c_int, _vp, C.c_int)
+_sig("ptrt_present_map", C.c_int, _vp, C.c_int, C.POINTER(_vp))
+_sig("ptrt_present_unmap", C.c_int, _vp, C.c_int)
+_sig("ptrt_present_acquire", C.c_int, _vp, C.c_int, C.POINTER(_vp))
+_sig("ptrt_present_destroy", C.c_int, _vp)
 _sig("hs_flatten", C.POINTER(SceneDesc), _vp)
 
 
@@ -430,6 +436,15 @@ class Scene:
         out = np.empty((self.tile_rows, self.width, 3), dtype=np.uint8)
         self._chk(lib.hs_render_to_host(self._h, out.ctypes.data_as(_vp)))
         return out
+
+    def view_run(self, frames, slots=2, keep=True, dump_prefix="", dump_every=0):
+        """The reference's viewer loop (map_pbo -> render_to_device -> unmap -> blit -> draw) over the HIP
+        presentation ring, headless.  Returns (frames as uint8 (n, H, W, 3) or None, wall ms per frame)."""
+        out = np.empty((frames, self.tile_rows, self.width, 3), dtype=np.uint8) if keep else None
+        ms = C.c_double()
+        self._chk(lib.hs_view_run(self._h, frames, slots, out.ctypes.data_as(_vp) if keep else None, C.byref(ms),
+                                  dump_prefix.encode(), dump_every))
+        return out, ms.value
 
     def sync(self): self._cchk(lib.ptrt_sync(self.ctx))
 

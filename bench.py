@@ -96,16 +96,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render loop has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # PTRT_BENCH_REHEARSE=1: dry run of the N > 1 code path on a ONE-GPU box -- every rank renders its band on
+    # cuda:0 and the gather goes through gloo with host staging.  Not a measurement (the JSON line says so).
+    rehearse = os.environ.get("PTRT_BENCH_REHEARSE") == "1" and world > 1
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ptrt_amd import tilefarm
     W, H = args.width, args.height
     y0, rows = tilefarm.bands(H, world)[rank]  # horizontal bands; the last rank takes the remainder rows
-    scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, local_rank)
+    scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, dev_index)
     scene.setSamplesPerPixel(args.spp)
     scene.setMaxBounceDepth(args.depth)
     if world == 1:
@@ -124,7 +131,7 @@ def main():
     tiles = [torch.empty((rows, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
     views = [None, None]
     if world > 1 and rank == 0:
-        frames = [torch.empty((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        frames = [torch.empty((H, W, 3), dtype=torch.uint8, device="cpu" if rehearse else "cuda") for _ in range(2)]
         views = [tilefarm.frame_views(f, H, world) for f in frames]
     pending = [None, None]
 
@@ -147,7 +154,10 @@ def main():
         if pending[b] is not None:
             pending[b].wait()
         scene.render_to_device(tiles[b].data_ptr())
-        pending[b] = tilefarm.gather_bands(dist, tiles[b], views[b], rank, world, H, async_op=True)
+        if rehearse:
+            tilefarm.gather_bands(dist, tiles[b].cpu(), views[b], rank, world, H)
+        else:
+            pending[b] = tilefarm.gather_bands(dist, tiles[b], views[b], rank, world, H, async_op=True)
 
     def fence():
         for b in (0, 1):
@@ -173,7 +183,7 @@ def main():
     kms = scene.kernel_ms_history(args.steps)
     kernel_ms = float(kms.mean()) if len(kms) else float("nan")
     if world > 1:
-        t = torch.tensor([dt, rays, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, rays, kernel_ms], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -203,6 +213,7 @@ def main():
     out = {
         "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        **({"rehearsal": "gloo + host staging on one GPU: NOT a measurement"} if rehearse else {}),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "fps": round(fps, 2),
         "rays_per_frame": round(rays / args.steps),

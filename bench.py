@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--present", type=int, default=0, metavar="SLOTS",
                     help="N=1 only, not the headline: after the timed loop also run the viewer loop (device frame -> pinned "
                          "host, SLOTS-deep ring) and report its PCIe-inclusive ms/frame as config.present_ms_per_frame")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="ptrt_set_option for A/B experiments (e.g. pair_trace=0); not for the headline")
     ap.add_argument("--rebuild", action="store_true",
                     help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
     args = ap.parse_args()
@@ -122,6 +124,9 @@ def main():
     scene.initBlueNoise()
     scene.uploadToGPU()
     scene.set_option("count_rays", 1)
+    for kv in args.opt:
+        name, _, value = kv.partition("=")
+        scene.set_option(name, int(value))
     # render on torch's current stream so the RCCL gather is ordered after the frame without host syncs
     stream = torch.cuda.current_stream()
     scene.set_stream(stream.cuda_stream)

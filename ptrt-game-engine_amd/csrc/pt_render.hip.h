@@ -133,6 +133,8 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
         pr.d = pd;
         float tb = T_FAR;
         int bi = -1;
+        // (software-pipelining these LDS reads one packet ahead was measured: 2.82 vs 2.75 ms -- with four
+        // waves per SIMD the latency is already covered and the extra live registers cost more)
         for (int i = 0; i < K.pair_max_leaf; ++i) {
             const int slot = mt.x + (i < mt.y ? i : 0);
             const float4 *tp = L.tris + slot * 3 + oi * PAIR_PAD;
@@ -615,10 +617,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
             b += __shfl_xor(b, off);
             c += __shfl_xor(c, off);
         }
+        // one slot of three counters per workgroup, plain read-modify-write (only this workgroup touches
+        // it within a launch; launches are ordered).  Three atomics per wave on three shared addresses
+        // serialised at the L2 atomic unit: 97 K of them took 1.2 ms per 1080p frame -- hidden behind a
+        // 2.7-ms trace, but the whole cost of a light frame (1 spp, 1 bounce: 1.19 ms -> 0.17 ms).
         if (lane == 0) {
-            atomicAdd(&K.counters[0], (unsigned long long)a);
-            atomicAdd(&K.counters[1], (unsigned long long)b);
-            atomicAdd(&K.counters[2], (unsigned long long)c);
+            unsigned long long *w = K.counters + (size_t)blockIdx.x * 3;
+            w[0] += (unsigned long long)a;
+            w[1] += (unsigned long long)b;
+            w[2] += (unsigned long long)c;
         }
     }
 }

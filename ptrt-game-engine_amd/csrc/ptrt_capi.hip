@@ -49,7 +49,8 @@ struct ptrt_ctx {
     int *d_object_id = nullptr;
     unsigned char *d_rgb8 = nullptr;
     unsigned char *last_rgb8 = nullptr; // where the last frame's RGB8 went
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr; // n_counter_slots x {extension rays, shadow rays, paths}
+    size_t n_counter_slots = 0;
     float2 *d_blue = nullptr;
     uint32_t *d_jump = nullptr;
     int n_jump = 0;
@@ -741,12 +742,13 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
     HIP_TRY(c, hipMalloc((void **)&c->d_depth, c->npix * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_object_id, c->npix * sizeof(int)));
     HIP_TRY(c, hipMalloc((void **)&c->d_rgb8, c->npix * 3));
-    HIP_TRY(c, hipMalloc((void **)&c->d_counters, 3 * sizeof(unsigned long long)));
+    c->n_counter_slots = (size_t)((c->W + 7) / 8) * ((c->rows + 7) / 8); // one slot of 3 per 8x8-pixel workgroup
+    HIP_TRY(c, hipMalloc((void **)&c->d_counters, c->n_counter_slots * 3 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc((void **)&c->d_blue, PTRT_BLUE_NOISE_FLOATS * sizeof(float)));
     HIP_TRY(c, hipMemsetAsync(c->d_rng, 0, c->npix * 6 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, c->npix * 3 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_rgb8, 0, c->npix * 3, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, c->n_counter_slots * 3 * sizeof(unsigned long long), c->stream));
     // the blue-noise table is all zeros until the application installs one (bluenoise.cuh:46,189)
     HIP_TRY(c, hipMemsetAsync(c->d_blue, 0, PTRT_BLUE_NOISE_FLOATS * sizeof(float), c->stream));
     c->last_rgb8 = c->d_rgb8;
@@ -1754,10 +1756,15 @@ int ptrt_get_stats(ptrt_ctx *c, ptrt_stats *out) {
         return fail(c, PTRT_E_INVALID, "ptrt_get_stats: bad argument");
     if (int rc = set_device(c))
         return rc;
-    unsigned long long h[3] = {0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof h, c->stream));
+    // per-workgroup slots (no atomics in the kernel, see pt_render.hip.h): summed here
+    std::vector<unsigned long long> slots(c->n_counter_slots * 3);
+    HIP_TRY(c, hipMemcpyAsync(slots.data(), c->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, slots.size() * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[3] = {0, 0, 0};
+    for (size_t i = 0; i < slots.size(); ++i)
+        h[i % 3] += slots[i];
     out->extension_rays = h[0];
     out->shadow_rays = h[1];
     out->paths = h[2];

@@ -43,6 +43,7 @@ lib.oracle_render.restype = C.c_int
 lib.oracle_tonemap.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
 lib.oracle_trace_rays.argtypes = [C.c_void_p, _fp, _fp, C.c_int, C.c_void_p]
 lib.oracle_any_hit.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int, C.POINTER(C.c_int32)]
+lib.oracle_taa_jitter.argtypes = [C.c_int, _fp]
 lib.oracle_detmath.argtypes = [C.c_int, _fp, _fp, C.c_int, _fp]
 lib.oracle_eval_bsdf.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp]
 lib.oracle_scatter.argtypes = [C.c_void_p, C.c_int, _fp, _fp, C.c_int, _up, _fp]
@@ -214,6 +215,12 @@ def upscale(image, out_w, out_h, in_w, in_h):
     src = np.ascontiguousarray(image, np.float32)
     out = np.zeros((out_w * out_h, 3), np.float32)
     lib.oracle_upscale(_f(out), _f(src), out_w, out_h, in_w, in_h)
+    return out
+
+
+def taa_jitter(frame_index):
+    out = np.zeros(2, np.float32)
+    lib.oracle_taa_jitter(int(frame_index), _f(out))
     return out
 
 

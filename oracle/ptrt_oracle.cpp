@@ -1649,6 +1649,9 @@ void oracle_any_hit(const ptrt_scene_desc *scene, const float *origins, const fl
     }
 }
 
+/* taa.cuh:41-61, exposed so tests can set it beside the reference's own getTAAJitter (oracle/_ref) */
+void oracle_taa_jitter(int frame_index, float *out2) { getTAAJitter(frame_index, out2[0], out2[1]); }
+
 /* deterministic math, exposed for tests: op 0 sin, 1 cos, 2 exp, 3 log, 4 pow(x,y) */
 void oracle_detmath(int op, const float *x, const float *y, int n, float *out) {
     for (int i = 0; i < n; ++i) {

@@ -1,0 +1,68 @@
+// ref_probe.cpp -- TEST INFRASTRUCTURE.  Driver TU for oracle/_ref/ref_probe: the part of the
+// reference that compiles here from its OWN, unmodified sources, where they lie under
+// /root/reference/src, with g++ and the real CUDA runtime headers this image happens to ship
+// (triton's bundled copy; nothing is stubbed).  That part is the curand-free headers:
+//
+//   common/bluenoise.cuh:79-177   BlueNoiseGenerator::generateBlueNoise2D  (the 64x64x2 table)
+//   pathtracer/rendering/taa.cuh:19-61   Halton-16 table + getTAAJitter
+//   pathtracer/scene/lights.cuh:12-22    Light (layout the C ABI's ptrt_light mirrors)
+//   common/vec3.cuh, common/ray.cuh      vec3 / Ray layout
+//
+// Everything else on the path includes <curand_kernel.h> (pathtracer/math/mathutils.cuh:11, pulled
+// in by common/mat4.cuh:6), which the image lacks, so it is unbuildable here and stays
+// "parity unpinned" (DESIGN.md section 5).  initBlueNoise() (cudaMemcpyToSymbol) is never
+// referenced; -ffunction-sections + --gc-sections drops it, so no CUDA library is needed.
+//
+// Output: one JSON document on stdout (tests/golden/make_ref_probe_golden.py stores it).
+#define BLUE_NOISE_IMPLEMENTATION
+#include "common/vec3.cuh"
+#include "common/ray.cuh"
+#include "common/bluenoise.cuh"
+#include "pathtracer/rendering/taa.cuh"
+#include "pathtracer/scene/lights.cuh"
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static uint32_t bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+int main(int argc, char **argv) {
+    const char *raw = argc > 1 ? argv[1] : nullptr;  // optional: write the table's raw floats here
+    std::vector<float> bn = BlueNoiseGenerator::generateBlueNoise2D(BLUE_NOISE_SIZE, 25);
+    if (raw) {
+        FILE *f = fopen(raw, "wb");
+        if (!f || fwrite(bn.data(), 4, bn.size(), f) != bn.size()) return 2;
+        fclose(f);
+    }
+    printf("{\n \"blue_noise\": {\"size\": %d, \"channels\": %d, \"count\": %zu, \"bits\": [", BLUE_NOISE_SIZE,
+           BLUE_NOISE_CHANNELS, bn.size());
+    for (size_t i = 0; i < bn.size(); ++i) printf("%s%u", i ? "," : "", bits(bn[i]));
+    printf("]},\n \"taa_jitter_bits\": [");
+    for (int f = 0; f < 64; ++f) {
+        float2 j = getTAAJitter(f);
+        printf("%s[%u,%u]", f ? "," : "", bits(j.x), bits(j.y));
+    }
+    printf("],\n \"taa_sequence_length\": %d,\n", TAA_SEQUENCE_LENGTH);
+    Light L;
+    printf(" \"layout\": {\"vec3\": %zu, \"Ray\": %zu, \"Light\": %zu, \"Light.type\": %zu, \"Light.position\": %zu, "
+           "\"Light.direction\": %zu, \"Light.color\": %zu, \"Light.intensity\": %zu, \"Light.range\": %zu, "
+           "\"Light.innerCone\": %zu, \"Light.outerCone\": %zu, \"Light.radius\": %zu},\n",
+           sizeof(vec3), sizeof(Ray), sizeof(Light), offsetof(Light, type), offsetof(Light, position),
+           offsetof(Light, direction), offsetof(Light, color), offsetof(Light, intensity), offsetof(Light, range),
+           offsetof(Light, innerCone), offsetof(Light, outerCone), offsetof(Light, radius));
+    printf(" \"light_defaults_bits\": {\"type\": %d, \"position\": [%u,%u,%u], \"direction\": [%u,%u,%u], "
+           "\"color\": [%u,%u,%u], \"intensity\": %u, \"range\": %u, \"innerCone\": %u, \"outerCone\": %u, \"radius\": %u},\n",
+           (int)L.type, bits(L.position.x), bits(L.position.y), bits(L.position.z), bits(L.direction.x),
+           bits(L.direction.y), bits(L.direction.z), bits(L.color.x), bits(L.color.y), bits(L.color.z),
+           bits(L.intensity), bits(L.range), bits(L.innerCone), bits(L.outerCone), bits(L.radius));
+    printf(" \"light_types\": {\"LIGHT_POINT\": %d, \"LIGHT_DIRECTIONAL\": %d, \"LIGHT_SPOT\": %d}\n}\n",
+           (int)LIGHT_POINT, (int)LIGHT_DIRECTIONAL, (int)LIGHT_SPOT);
+    return 0;
+}

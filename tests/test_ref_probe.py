@@ -1,0 +1,69 @@
+"""The part of the oracle that IS pinned by the reference's own code: oracle/_ref/ref_probe is the
+reference's curand-free headers compiled here unmodified (oracle/ref_probe.cpp); its output is
+committed as tests/golden/ref_probe.json.  The restatements the render path feeds on -- blue-noise
+table, TAA jitter, Light layout and defaults -- must reproduce it bit for bit."""
+import ctypes
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "ref_probe.json")))
+EXE = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "ref_probe")
+
+
+def test_golden_is_what_the_reference_build_prints():
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref not built (needs /root/reference: make -C oracle ref)")
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(HERE, "golden", "make_ref_probe_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    assert mk.run_probe() == GOLD
+
+
+def test_blue_noise_table_is_the_reference_generators(P):
+    bn = np.ascontiguousarray(P.blue_noise_table(), dtype=np.float32).reshape(-1)
+    g = GOLD["blue_noise"]
+    assert bn.size == g["count"] == g["size"] * g["size"] * g["channels"]
+    assert [int(v) for v in bn.view(np.uint32)[:64]] == g["first64_bits"]
+    assert hashlib.sha256(bn.tobytes()).hexdigest() == g["sha256"]
+
+
+def test_taa_jitter_matches_reference_for_64_frames(O):
+    assert GOLD["taa_sequence_length"] == 16
+    for f, want in enumerate(GOLD["taa_jitter_bits"]):
+        got = [int(v) for v in O.taa_jitter(f).view(np.uint32)]
+        assert got == want, f
+    # entry 15 repeats x = 0.0625 (taa.cuh:35): frames 7 and 15 share their x jitter
+    assert GOLD["taa_jitter_bits"][7][0] == GOLD["taa_jitter_bits"][15][0]
+
+
+def test_light_layout_and_defaults(P):
+    lay = GOLD["layout"]
+    assert ctypes.sizeof(P.Vec3) == lay["vec3"] and ctypes.sizeof(P.Light) == lay["Light"]
+    names = {"type": "type", "position": "position", "direction": "direction", "color": "color",
+             "intensity": "intensity", "range": "range", "innerCone": "inner_cone", "outerCone": "outer_cone",
+             "radius": "radius"}
+    for ref, ours in names.items():
+        assert getattr(P.Light, ours).offset == lay[f"Light.{ref}"], ref
+    t = GOLD["light_types"]
+    assert (t["LIGHT_POINT"], t["LIGHT_DIRECTIONAL"], t["LIGHT_SPOT"]) == (0, 1, 2)
+    # a directional light leaves position/range/cones/radius at Light()'s defaults
+    s = P.Scene(64, 64, device=P.HOST_ONLY)
+    s.addCube(P.Material(albedo=(0.5, 0.5, 0.5), roughness=0.5))
+    s.addDirectionalLight((0.0, -1.0, 0.0), (1.0, 1.0, 1.0), 1.0)
+    L = ctypes.cast(s.flatten(), ctypes.POINTER(P.SceneDesc)).contents.lights[0]
+    bits = lambda x: int(np.float32(x).view(np.uint32))
+    d = GOLD["light_defaults_bits"]
+    assert L.type == t["LIGHT_DIRECTIONAL"]
+    assert [bits(L.position.x), bits(L.position.y), bits(L.position.z)] == d["position"]
+    assert [bits(L.direction.x), bits(L.direction.y), bits(L.direction.z)] == d["direction"]
+    assert [bits(L.color.x), bits(L.color.y), bits(L.color.z)] == d["color"]
+    for ref, ours in (("intensity", "intensity"), ("range", "range"), ("innerCone", "inner_cone"),
+                      ("outerCone", "outer_cone"), ("radius", "radius")):
+        assert bits(getattr(L, ours)) == d[ref], ref
+    s.close()

@@ -58,6 +58,39 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes) {
     return l;
 }
 
+// Traversal statistics (build with -DPT_TRAV_STATS; read with ptrt_debug_trav_stats): how full the
+// wave is in each loop of the PMODE 2 traversals.  [0..7] closest, [8..15] any-hit:
+// calls, pairs, node wave-iterations, node lane-steps, leaf phases, triangle wave-iterations,
+// triangle lane-tests, outer iterations; [16] persistent-loop iterations, [17] live lanes in them.
+__device__ unsigned long long g_trav_stats[24];
+#ifdef PT_TRAV_STATS
+struct TravStats {
+    unsigned v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PT_DEV void wave(int i, int lane) { // once per wave-level execution of the enclosing block
+        if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+            ++v[i];
+    }
+    PT_DEV void lanes(int i) { ++v[i]; }
+    PT_DEV void flush(int base, int lane) {
+        for (int i = 0; i < 8; ++i) {
+            unsigned a = v[i];
+            for (int off = 32; off > 0; off >>= 1)
+                a += __shfl_xor(a, off);
+            if (lane == 0 && a)
+                atomicAdd(&g_trav_stats[base + i], (unsigned long long)a);
+        }
+    }
+};
+#define TS_WAVE(i) ts.wave(i, lane)
+#define TS_LANE(i) ts.lanes(i)
+#else
+struct TravStats {
+    PT_DEV void flush(int, int) {}
+};
+#define TS_WAVE(i)
+#define TS_LANE(i)
+#endif
+
 PT_DEV int lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -311,6 +344,251 @@ PT_DEV bool any_hit_pairs_bvh(const KParams &K, const PairLds &L, int lane, bool
     return occluded;
 }
 
+// PMODE 2 with dynamic refill.  A batch of 64 pairs runs as long as its LONGEST traversal while the
+// lanes whose pair missed after three nodes idle (measured on the showcase scene: 17 % of the VALU lanes
+// busy).  Here the pair list is a queue: whenever K.fetch_min lanes are idle (or all are), the idle
+// lanes take the next pairs -- rank by ballot/mbcnt, `next` is wave-uniform, no atomics -- commit
+// their finished pair with the same 64-bit min and start over, while the other lanes keep their
+// traversal state.  Every pair is still traversed exactly as before, so the bits cannot change.
+PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
+    const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
+    LdsStack stk{L.stack + lane};
+    __syncthreads();
+    int next = 0;
+    bool busy = false, active = false, xf = false;
+    int cur = 0, sp = 0, r = 0, oi = 0, sb = -1;
+    float dirScale = 1.0f, tb = T_FAR;
+    RayO pr = make_ray(o, d);
+    TravStats ts;
+    auto pop = [&]() {
+        active = false;
+        while (sp > 0) {
+            --sp;
+            int ref;
+            float tE;
+            stk.pop(sp, ref, tE);
+            if (tE < tb) {
+                cur = ref;
+                active = true;
+                break;
+            }
+        }
+    };
+    for (;;) {
+        TS_WAVE(7);
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+        const int n_idle = __builtin_popcountll(idle);
+        if (next < P && (n_idle >= K.fetch_min || n_idle == 64)) {
+            const int p = next + lane_prefix(idle);
+            if (!busy && p < P) {
+                const uint32_t e = L.pairs[p];
+                r = (int)(e & 63u);
+                oi = (int)(e >> 8);
+                const int4 mt = L.meshtab[oi];
+                f3 po, pd;
+                pair_ray(K, L, r, mt, po, pd, dirScale);
+                pr = make_ray(po, pd);
+                xf = (mt.z & 1) != 0;
+                cur = mt.x;
+                sp = 0;
+                tb = T_FAR;
+                sb = -1;
+                busy = active = true;
+            }
+            next += n_idle;
+        }
+        if (!__builtin_amdgcn_ballot_w64(busy))
+            break;
+        while (active && cur >= 0) {
+            TS_WAVE(2);
+            TS_LANE(3);
+            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
+                         n3 = K.nodes[cur * 4 + 3];
+            float tL, tR;
+            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tb, tL);
+            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tb, tR);
+            const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+            if (hL || hR) {
+                const bool nearL = hL && (!hR || tL <= tR);
+                if (nearL ? hR : hL) {
+                    stk.push(sp, nearL ? Rr : Lr, nearL ? tR : tL);
+                    ++sp;
+                }
+                cur = nearL ? Lr : Rr;
+            } else {
+                pop();
+            }
+        }
+        if (active) { // cur is a leaf
+            TS_WAVE(4);
+            const int2 lf = K.leaves[~cur];
+            const float4 *tp = K.tris + (size_t)lf.x * 3;
+            float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+            if (lf.y > 0) {
+                p0 = tp[0];
+                p1 = tp[1];
+                p2 = tp[2];
+            }
+            for (int i = 0; i < lf.y; ++i) {
+                TS_WAVE(5);
+                TS_LANE(6);
+                const int nx = (i + 1 < lf.y) ? (i + 1) : i;
+                const float4 q0 = tp[nx * 3 + 0], q1 = tp[nx * 3 + 1], q2 = tp[nx * 3 + 2];
+                float t, u, v;
+                if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tb, t, u, v)) {
+                    tb = t;
+                    sb = lf.x + i;
+                }
+                p0 = q0;
+                p1 = q1;
+                p2 = q2;
+            }
+            pop();
+        }
+        if (busy && !active) { // this pair is finished: merge it into its ray
+            if (sb >= 0) {
+                const float tw = xf ? tb / dirScale : tb;
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)oi << 24) | (uint32_t)sb;
+                __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            busy = false;
+        }
+    }
+#ifdef PT_TRAV_STATS
+    ts.v[0] = lane == 0 ? 1u : 0u;
+    ts.v[1] = lane == 0 ? (unsigned)P : 0u;
+#endif
+    ts.flush(0, lane);
+    __syncthreads();
+    const unsigned long long key = L.best[lane];
+    __syncthreads();
+    Hit h;
+    h.u = h.v = 0.0f;
+    if (!alive || key == ~0ull) {
+        h.t = h.t_local = T_FAR;
+        h.mesh = -1;
+        h.slot = -1;
+        return h;
+    }
+    const int4 mt = L.meshtab[(int)((key >> 24) & 0xffu)];
+    h.t = __uint_as_float((uint32_t)(key >> 32));
+    h.mesh = mt.w;
+    h.slot = (int)(key & 0xffffffu);
+    h.t_local = h.t;
+    if (mt.z & 1) {
+        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
+        RayO lr;
+        lr.o = xform_point(rec[2], rec[3], rec[4], o);
+        lr.d = normalize(xform_dir(rec[2], rec[3], rec[4], d));
+        const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
+        float t, u, v;
+        tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), lr, T_FAR, t, u, v);
+        h.t_local = t;
+    }
+    return h;
+}
+
+// Any hit, same queue.  A pair whose ray is already known to be occluded is dropped at refill (the
+// answer is an OR over the ray's pairs).
+PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
+    const int P = build_pairs<true>(K, L, lane, alive, o, d, tMax);
+    LdsStack stk{L.stack + lane};
+    float *tmaxv = (float *)L.best;
+    tmaxv[lane] = tMax;
+    __syncthreads();
+    int next = 0;
+    bool busy = false;
+    int cur = 0, sp = 0, r = 0;
+    float tm = 0.0f;
+    RayO pr = make_ray(o, d);
+    TravStats ts;
+    auto pop = [&]() {
+        busy = false;
+        if (sp > 0) {
+            --sp;
+            float tE;
+            stk.pop(sp, cur, tE);
+            busy = true;
+        }
+    };
+    for (;;) {
+        TS_WAVE(7);
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+        const int n_idle = __builtin_popcountll(idle);
+        if (next < P && (n_idle >= K.fetch_min || n_idle == 64)) {
+            const int p = next + lane_prefix(idle);
+            if (!busy && p < P) {
+                const uint32_t e = L.pairs[p];
+                r = (int)(e & 63u);
+                if (L.occ[r] == 0u) {
+                    const int4 mt = L.meshtab[(int)(e >> 8)];
+                    f3 po, pd;
+                    float dirScale;
+                    pair_ray(K, L, r, mt, po, pd, dirScale);
+                    pr = make_ray(po, pd);
+                    tm = tmaxv[r];
+                    if (mt.z & 1)
+                        tm = tm * dirScale;
+                    cur = mt.x;
+                    sp = 0;
+                    busy = true;
+                }
+            }
+            next += n_idle;
+        }
+        if (!__builtin_amdgcn_ballot_w64(busy))
+            break;
+        while (busy && cur >= 0) {
+            TS_WAVE(2);
+            TS_LANE(3);
+            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
+                         n3 = K.nodes[cur * 4 + 3];
+            float tL, tR;
+            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tm, tL);
+            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tm, tR);
+            const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+            if (hL && hR) {
+                stk.push(sp, Rr, 0.0f);
+                ++sp;
+                cur = Lr;
+            } else if (hL || hR) {
+                cur = hL ? Lr : Rr;
+            } else {
+                pop();
+            }
+        }
+        if (busy) { // cur is a leaf
+            TS_WAVE(4);
+            const int2 lf = K.leaves[~cur];
+            bool found = false;
+            for (int i = 0; i < lf.y; ++i) {
+                TS_WAVE(5);
+                TS_LANE(6);
+                const int slot = lf.x + i;
+                const float4 p0 = K.tris[slot * 3 + 0], p1 = K.tris[slot * 3 + 1], p2 = K.tris[slot * 3 + 2];
+                float t, u, v;
+                found |= tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tm, t, u, v);
+            }
+            if (found) {
+                L.occ[r] = 1u;
+                busy = false;
+            } else {
+                pop();
+            }
+        }
+    }
+#ifdef PT_TRAV_STATS
+    ts.v[0] = lane == 0 ? 1u : 0u;
+    ts.v[1] = lane == 0 ? (unsigned)P : 0u;
+#endif
+    ts.flush(8, lane);
+    __syncthreads();
+    const bool occluded = alive && (L.occ[lane] != 0u);
+    __syncthreads();
+    return occluded;
+}
+
 // ---------------------------------------------------------------------------------
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 3
@@ -381,6 +659,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
 
     while (__builtin_amdgcn_ballot_w64(s < K.spp)) {
         const bool live = s < K.spp;
+#ifdef PT_TRAV_STATS
+        {
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+            if (lane == 0) {
+                atomicAdd(&g_trav_stats[16], 1ull);
+                atomicAdd(&g_trav_stats[17], (unsigned long long)__builtin_popcountll(lm));
+            }
+        }
+#endif
         // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
         if (live && fresh) {
             float tjx, tjy, bnx, bny;
@@ -417,7 +704,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
 
         // ---- [B] closest hit, all live lanes together
         const Hit h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd)
-                      : (PMODE == 2) ? closest_hit_pairs_bvh(K, PL, lane, live, ro, rd)
+                      : (PMODE == 2) ? (K.fetch_min > 0 ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
+                                                        : closest_hit_pairs_bvh(K, PL, lane, live, ro, rd))
                                      : closest_hit<GEOM>(K, live, ro, rd, stk);
 
         // ---- [C] first half of the shading
@@ -530,7 +818,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         bool in_shadow = false;
         if (__builtin_amdgcn_ballot_w64(want_shadow)) {
             in_shadow = (PMODE == 1)   ? any_hit_pairs(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
-                        : (PMODE == 2) ? any_hit_pairs_bvh(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
+                        : (PMODE == 2) ? (K.fetch_min > 0 ? any_hit_pairs_dyn(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
+                                                          : any_hit_pairs_bvh(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax))
                                        : any_hit<GEOM>(K, want_shadow, shadow_o, L, shadow_tmax, stk);
         }
 

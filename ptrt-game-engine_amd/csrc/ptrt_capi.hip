@@ -130,7 +130,7 @@ struct ptrt_ctx {
     hipStream_t present_stream = nullptr;
 
     // options
-    int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1;
+    int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16;
     bool timed = false;
 };
 
@@ -385,6 +385,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.pair_meshes = c->pair_meshes;
     K.pair_tri_slots = c->pair_tri_slots;
     K.pair_max_leaf = c->pair_max_leaf;
+    K.fetch_min = c->fetch_min;
     K.cam = c->cam;
     K.sky_top = c->sky_top;
     K.sky_bottom = c->sky_bottom;
@@ -1785,7 +1786,11 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->force_full = value ? 1 : 0;
     else if (n == "pair_trace") // 0: lock-step mesh loop instead of (ray, mesh) pair compaction (A/B, tests)
         c->pair_trace = value ? 1 : 0;
-    else if (n == "denoiser_active") // perfSettings.enableDenoiser: use the (already allocated) denoiser or not
+    else if (n == "fetch_min") { // PMODE 2: refill threshold in idle lanes; 0 = static batches of 64 pairs (A/B, tests)
+        if (value < 0 || value > 64)
+            return fail(c, PTRT_E_INVALID, "fetch_min must be 0..64");
+        c->fetch_min = (int)value;
+    } else if (n == "denoiser_active") // perfSettings.enableDenoiser: use the (already allocated) denoiser or not
         c->dn_active = value ? 1 : 0;
     else if (n == "motion_vectors") // perfSettings.enableMotionVectors
         c->mv_active = value ? 1 : 0;
@@ -1793,6 +1798,20 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->use_graphs = value ? 1 : 0;
     else
         return fail(c, PTRT_E_INVALID, "unknown option '%s'", name);
+    return PTRT_OK;
+}
+
+// profiling hook (not part of the drop-in surface): reads and clears pt::g_trav_stats; all zero unless
+// the library was built with -DPT_TRAV_STATS
+int ptrt_debug_trav_stats(ptrt_ctx *c, unsigned long long *out24) {
+    if (!ctx_live(c) || !out24)
+        return fail(c, PTRT_E_INVALID, "ptrt_debug_trav_stats: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out24, HIP_SYMBOL(pt::g_trav_stats), 24 * sizeof(unsigned long long)));
+    unsigned long long zero[24] = {};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(pt::g_trav_stats), zero, sizeof(zero)));
     return PTRT_OK;
 }
 

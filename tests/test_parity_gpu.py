@@ -90,6 +90,29 @@ def test_showcase_small(P, O, blue_noise):
     s.close()
 
 
+@pytest.mark.parametrize("fetch_min", [0, 1, 16, 48, 64])
+def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min):
+    """PMODE 2 (deep BLASes behind a single-leaf TLAS): static 64-pair batches (0) and the dynamic
+    refill at every threshold give the oracle's bits -- showcase materials, plus instanced meshes."""
+    s = P.Scene(96, 64)
+    P.scenes.showcase(s, segments=12)
+    s.set_option("fetch_min", fetch_min)
+    gpu, cpu = render_both(P, O, s, blue_noise, 2, 5, 2)
+    assert_frames_equal(gpu, cpu)
+    s.close()
+    s = P.Scene(72, 64)
+    P.scenes.cornell(s)
+    extra = s.addCube(P.Material((0.2, 0.3, 0.9), 0.4))
+    s.setPosition(extra, (1.0, -1.0, -5.0))
+    s.setRotation(extra, (0.3, 0.5, 0.1))
+    s.setInstanceScale(extra, (1.5, 0.7, 1.2))
+    s.setBVHLeafTarget(2, 0)
+    s.set_option("fetch_min", fetch_min)
+    gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
+    assert_frames_equal(gpu, cpu)
+    s.close()
+
+
 def test_tile_equals_full_frame(P, O, blue_noise):
     """Rows [24,40) rendered alone are the same bits as those rows of the full frame (global RNG keying)."""
     full = P.Scene(64, 64)

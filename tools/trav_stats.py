@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Lane-occupancy statistics of the PMODE 2 traversals (library built with -DPT_TRAV_STATS):
+   PTRT_AMD_LIB=ptrt-game-engine_amd/build/variants/libptrt_stats.so python tools/trav_stats.py [scene] [W H spp]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ptrt-game-engine_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+assert torch.cuda.is_available(), "needs a HIP device"
+torch.cuda.set_device(0)
+import ptrt_amd as P  # noqa: E402
+from bench import build_scene  # noqa: E402
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "showcase"
+W, H, spp = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (1920, 1080, 4)
+s = build_scene(P, scene, W, H, 0, 0, 0)
+s.setSamplesPerPixel(spp)
+s.setMaxBounceDepth(4)
+s.initBlueNoise()
+s.uploadToGPU()
+s.set_option("count_rays", 1)
+for kv in sys.argv[5:]:
+    k, _, v = kv.partition("=")
+    s.set_option(k, int(v))
+buf = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+out = (C.c_ulonglong * 24)()
+P.lib.ptrt_debug_trav_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+P.lib.ptrt_debug_trav_stats(s.ctx, out)
+s.stats()
+s.render_to_device(buf.data_ptr())
+torch.cuda.synchronize()
+assert P.lib.ptrt_debug_trav_stats(s.ctx, out) == 0
+st = s.stats()
+v = list(out)
+print("rays", st)
+for name, b in (("closest", 0), ("any-hit", 8)):
+    calls, pairs, nw, nl, lp, tw, tl, outer = v[b:b + 8]
+    if not calls:
+        continue
+    print(f"{name}: calls {calls}  pairs/call {pairs / calls:.1f}  outer iters/call {outer / calls:.2f}")
+    print(f"   node steps: {nw / calls:.1f} wave-iterations/call, lanes busy {100.0 * nl / max(1, nw * 64):.1f} %  "
+          f"({nl / max(1, pairs):.1f} nodes per pair)")
+    print(f"   leaf phases/call {lp / calls:.1f}; triangle loop: {tw / calls:.1f} wave-iterations/call, lanes busy "
+          f"{100.0 * tl / max(1, tw * 64):.1f} %  ({tl / max(1, pairs):.1f} triangles per pair)")
+print(f"persistent loop: {v[16]} iterations, live lanes {100.0 * v[17] / max(1, v[16] * 64):.1f} %")

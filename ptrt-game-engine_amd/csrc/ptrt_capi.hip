@@ -12,6 +12,7 @@
 #include "pt_post.hip.h"
 #include "pt_refit.hip.h"
 #include "pt_render.hip.h"
+#include "pt_wavefront.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -128,6 +129,16 @@ struct ptrt_ctx {
     };
     std::vector<PresentSlot> present;
     hipStream_t present_stream = nullptr;
+
+    // wavefront stages (pt_wavefront.hip.h): per-path state, planar, tile-ordered
+    int wavefront = 0; // option: 1 = render scenes with a single-leaf TLAS through the trace/shade stages
+    uint32_t *wf_st = nullptr, *wf_occ = nullptr, *wf_live = nullptr;
+    float *wf_planes = nullptr; // 25 planes: ray 6, thr 3, acc 3, avg 3, pend 3, shadow ray 7
+    float4 *wf_hit = nullptr;
+    size_t wf_items = 0;
+    int wf_trace_blocks = 0;
+    size_t wf_trace_lds = 0;
+    int last_mode = 0; // how the last frame was rendered: 0 megakernel, 1 wavefront stages
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16;
@@ -444,6 +455,76 @@ int pair_mode(const ptrt_ctx *c, int geom) {
     return 0;
 }
 
+// ---- wavefront stages ------------------------------------------------------------------------
+constexpr int WF_MAX_ITERS = 16 * 17 + 2; // spp and max_depth are clamped to 16 by the Scene mirror; larger frames fall back
+
+bool wavefront_applicable(const ptrt_ctx *c, int spp, int max_depth) {
+    if (!c->wavefront || !c->tlas_single_leaf || c->pair_meshes <= 0 || c->pair_meshes > 64)
+        return false;
+    if (spp > 255 || max_depth > 255 || spp * (max_depth + 1) + 2 > WF_MAX_ITERS)
+        return false;
+    return (size_t)4 * ((size_t)c->stack_entries * 64 + pt::WF_RING / 2) * sizeof(uint2) <= 64 * 1024;
+}
+
+int run_wavefront(ptrt_ctx *c, const pt::KParams &K, bool full, int spp, int max_depth) {
+    const int tiles_y = (K.rows + 7) / 8;
+    const size_t items = (size_t)K.tiles_x * tiles_y * 64;
+    if (items > c->wf_items) {
+        dfree(c->wf_st);
+        dfree(c->wf_occ);
+        dfree(c->wf_planes);
+        dfree(c->wf_hit);
+        c->wf_items = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->wf_st, items * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->wf_occ, items * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->wf_planes, items * 25 * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void **)&c->wf_hit, items * sizeof(float4)));
+        c->wf_items = items;
+    }
+    if (!c->wf_live)
+        HIP_TRY(c, hipMalloc((void **)&c->wf_live, WF_MAX_ITERS * sizeof(uint32_t)));
+    const size_t lds = (size_t)4 * ((size_t)c->stack_entries * 64 + pt::WF_RING / 2) * sizeof(uint2);
+    if (!c->wf_trace_blocks || c->wf_trace_lds != lds) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt::wf_trace_kernel, 256, lds));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (per_cu < 1 || cus < 1)
+            return fail(c, PTRT_E_HIP, "wavefront trace kernel does not fit (LDS %zu bytes)", lds);
+        c->wf_trace_blocks = per_cu * cus;
+        c->wf_trace_lds = lds;
+    }
+    pt::WfParams W{};
+    W.st = c->wf_st;
+    W.occ = c->wf_occ;
+    W.live = c->wf_live;
+    W.hit = c->wf_hit;
+    float *p = c->wf_planes;
+    W.ray = p;
+    W.thr = p + 6 * items;
+    W.acc = p + 9 * items;
+    W.avg = p + 12 * items;
+    W.pend = p + 15 * items;
+    W.sh = p + 18 * items;
+    W.n_items = (int)items;
+    W.fetch_min = c->fetch_min > 0 ? c->fetch_min : 16;
+    const int iters = spp * (max_depth + 1);
+    HIP_TRY(c, hipMemsetAsync(c->wf_live, 0, (size_t)(iters + 2) * sizeof(uint32_t), c->stream));
+    const int shade_blocks = (int)((items + 255) / 256);
+    const int chunks = (int)(items / 64);
+    const int trace_blocks = std::min(c->wf_trace_blocks, (chunks + 3) / 4);
+    for (int it = 0; it <= iters; ++it) {
+        W.iter = it;
+        if (it > 0)
+            hipLaunchKernelGGL(pt::wf_trace_kernel, dim3(trace_blocks), dim3(256), lds, c->stream, K, W);
+        if (full)
+            hipLaunchKernelGGL(pt::wf_shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, c->stream, K, W);
+        else
+            hipLaunchKernelGGL(pt::wf_shade_kernel<false>, dim3(shade_blocks), dim3(256), 0, c->stream, K, W);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return PTRT_OK;
+}
+
 bool ctx_live(ptrt_ctx *c) {
     std::lock_guard<std::mutex> lock(g_live_mutex);
     return c && g_live.count(c);
@@ -744,6 +825,7 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
     HIP_TRY(c, hipMalloc((void **)&c->d_object_id, c->npix * sizeof(int)));
     HIP_TRY(c, hipMalloc((void **)&c->d_rgb8, c->npix * 3));
     c->n_counter_slots = (size_t)((c->W + 7) / 8) * ((c->rows + 7) / 8); // one slot of 3 per 8x8-pixel workgroup
+    c->n_counter_slots += 4; // the shade stage uses one slot per wave of a 256-thread grid (rounded up)
     HIP_TRY(c, hipMalloc((void **)&c->d_counters, c->n_counter_slots * 3 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc((void **)&c->d_blue, PTRT_BLUE_NOISE_FLOATS * sizeof(float)));
     HIP_TRY(c, hipMemsetAsync(c->d_rng, 0, c->npix * 6 * sizeof(uint32_t), c->stream));
@@ -788,6 +870,11 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_object_id);
     dfree(c->d_rgb8);
     dfree(c->d_counters);
+    dfree(c->wf_st);
+    dfree(c->wf_occ);
+    dfree(c->wf_live);
+    dfree(c->wf_planes);
+    dfree(c->wf_hit);
     dfree(c->d_blue);
     dfree(c->d_jump);
     dfree(c->d_env);
@@ -1460,7 +1547,12 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
     const int slot = (int)(c->launches % EV_RING);
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
-    if (pmode == 1)
+    c->last_mode = 0;
+    if (wavefront_applicable(c, spp, max_depth)) {
+        if (int rc = run_wavefront(c, K, full, spp, max_depth))
+            return rc;
+        c->last_mode = 1;
+    } else if (pmode == 1)
         launch_trace<0, 1>(c, K, full, grid, lds);
     else if (pmode == 2)
         launch_trace<1, 2>(c, K, full, grid, lds);
@@ -1786,6 +1878,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->force_full = value ? 1 : 0;
     else if (n == "pair_trace") // 0: lock-step mesh loop instead of (ray, mesh) pair compaction (A/B, tests)
         c->pair_trace = value ? 1 : 0;
+    else if (n == "wavefront") // 1: trace/shade stages over the whole frame's rays instead of the megakernel
+        c->wavefront = value ? 1 : 0;
     else if (n == "fetch_min") { // PMODE 2: refill threshold in idle lanes; 0 = static batches of 64 pairs (A/B, tests)
         if (value < 0 || value > 64)
             return fail(c, PTRT_E_INVALID, "fetch_min must be 0..64");
@@ -1800,6 +1894,9 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         return fail(c, PTRT_E_INVALID, "unknown option '%s'", name);
     return PTRT_OK;
 }
+
+// test hook: which kernels rendered the last frame (0 megakernel, 1 wavefront stages)
+int ptrt_debug_last_render_mode(ptrt_ctx *c) { return ctx_live(c) ? c->last_mode : -1; }
 
 // profiling hook (not part of the drop-in surface): reads and clears pt::g_trav_stats; all zero unless
 // the library was built with -DPT_TRAV_STATS

@@ -13,6 +13,7 @@
 #include "pt_refit.hip.h"
 #include "pt_render.hip.h"
 #include "pt_wavefront.hip.h"
+#include "pt_async.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -138,7 +139,12 @@ struct ptrt_ctx {
     size_t wf_items = 0;
     int wf_trace_blocks = 0;
     size_t wf_trace_lds = 0;
-    int last_mode = 0; // how the last frame was rendered: 0 megakernel, 1 wavefront stages
+    int last_mode = 0; // how the last frame was rendered: 0 megakernel, 1 wavefront stages, 2 asynchronous lanes
+    // asynchronous-lane megakernel (pt_async.hip.h)
+    int async_lanes = 0, shade_min = 32, leaf_min = 24; // options
+    uint32_t *as_cursor = nullptr;
+    int as_blocks[2] = {0, 0}; // resident workgroups of the <false>/<true> kernel at as_lds bytes of LDS
+    size_t as_lds = 0;
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16;
@@ -525,6 +531,46 @@ int run_wavefront(ptrt_ctx *c, const pt::KParams &K, bool full, int spp, int max
     return PTRT_OK;
 }
 
+// ---- asynchronous-lane megakernel -------------------------------------------------------------
+bool async_applicable(const ptrt_ctx *c) {
+    if (!c->async_lanes || !c->tlas_single_leaf || c->pair_meshes <= 0 || c->pair_meshes > 64)
+        return false;
+    return ((size_t)c->stack_entries * 64 + pt::AS_RING / 2) * sizeof(uint2) <= 40 * 1024;
+}
+
+int run_async(ptrt_ctx *c, const pt::KParams &K, bool full) {
+    const size_t lds = ((size_t)c->stack_entries * 64 + pt::AS_RING / 2) * sizeof(uint2);
+    if (!c->as_cursor)
+        HIP_TRY(c, hipMalloc((void **)&c->as_cursor, sizeof(uint32_t)));
+    if (c->as_lds != lds || !c->as_blocks[full ? 1 : 0]) {
+        if (c->as_lds != lds)
+            c->as_blocks[0] = c->as_blocks[1] = 0;
+        int per_cu = 0, cus = 0;
+        if (full)
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt::path_trace_async_kernel<true>, 64, lds));
+        else
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt::path_trace_async_kernel<false>, 64, lds));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (per_cu < 1 || cus < 1)
+            return fail(c, PTRT_E_HIP, "asynchronous trace kernel does not fit (LDS %zu bytes)", lds);
+        c->as_blocks[full ? 1 : 0] = per_cu * cus;
+        c->as_lds = lds;
+    }
+    pt::AsyncParams A{};
+    A.cursor = c->as_cursor;
+    A.n_tiles = K.tiles_x * ((K.rows + 7) / 8);
+    A.shade_min = c->shade_min;
+    A.leaf_min = c->leaf_min;
+    const int grid = std::min(c->as_blocks[full ? 1 : 0], A.n_tiles);
+    HIP_TRY(c, hipMemsetAsync(c->as_cursor, 0, sizeof(uint32_t), c->stream));
+    if (full)
+        hipLaunchKernelGGL(pt::path_trace_async_kernel<true>, dim3(grid), dim3(64), lds, c->stream, K, A);
+    else
+        hipLaunchKernelGGL(pt::path_trace_async_kernel<false>, dim3(grid), dim3(64), lds, c->stream, K, A);
+    HIP_TRY(c, hipGetLastError());
+    return PTRT_OK;
+}
+
 bool ctx_live(ptrt_ctx *c) {
     std::lock_guard<std::mutex> lock(g_live_mutex);
     return c && g_live.count(c);
@@ -875,6 +921,7 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->wf_live);
     dfree(c->wf_planes);
     dfree(c->wf_hit);
+    dfree(c->as_cursor);
     dfree(c->d_blue);
     dfree(c->d_jump);
     dfree(c->d_env);
@@ -1548,7 +1595,11 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const int slot = (int)(c->launches % EV_RING);
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
     c->last_mode = 0;
-    if (wavefront_applicable(c, spp, max_depth)) {
+    if (async_applicable(c)) {
+        if (int rc = run_async(c, K, full))
+            return rc;
+        c->last_mode = 2;
+    } else if (wavefront_applicable(c, spp, max_depth)) {
         if (int rc = run_wavefront(c, K, full, spp, max_depth))
             return rc;
         c->last_mode = 1;
@@ -1878,7 +1929,17 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->force_full = value ? 1 : 0;
     else if (n == "pair_trace") // 0: lock-step mesh loop instead of (ray, mesh) pair compaction (A/B, tests)
         c->pair_trace = value ? 1 : 0;
-    else if (n == "wavefront") // 1: trace/shade stages over the whole frame's rays instead of the megakernel
+    else if (n == "async_lanes") // 1: persistent megakernel with asynchronous lanes for single-leaf-TLAS scenes
+        c->async_lanes = value ? 1 : 0;
+    else if (n == "shade_min") { // async_lanes: lanes that wait for the shading block before it runs
+        if (value < 1 || value > 64)
+            return fail(c, PTRT_E_INVALID, "shade_min must be 1..64");
+        c->shade_min = (int)value;
+    } else if (n == "leaf_min") { // async_lanes: lanes waiting at a leaf that end the node loop
+        if (value < 1 || value > 64)
+            return fail(c, PTRT_E_INVALID, "leaf_min must be 1..64");
+        c->leaf_min = (int)value;
+    } else if (n == "wavefront") // 1: trace/shade stages over the whole frame's rays instead of the megakernel
         c->wavefront = value ? 1 : 0;
     else if (n == "fetch_min") { // PMODE 2: refill threshold in idle lanes; 0 = static batches of 64 pairs (A/B, tests)
         if (value < 0 || value > 64)

@@ -36,6 +36,15 @@ assert P.lib.ptrt_debug_trav_stats(s.ctx, out) == 0
 st = s.stats()
 v = list(out)
 print("rays", st)
+if any(kv.startswith("async_lanes=1") for kv in sys.argv[5:]):
+    it, sr, sl, mr, ml, nw, nl, _, tw, tl, tr = v[:11]
+    print(f"async: main-loop iterations {it} ({it / (st['extension_rays'] + st['shadow_rays']) * 64:.1f} per 64 rays), "
+          f"lanes tracing {100.0 * tr / max(1, it * 64):.1f} %")
+    print(f"   shading block: {sr} runs ({100.0 * sr / it:.1f} % of iterations), lanes shading {100.0 * sl / max(1, sr * 64):.1f} %")
+    print(f"   between-mesh block: {mr} runs ({100.0 * mr / it:.1f} % of iterations), lanes {100.0 * ml / max(1, mr * 64):.1f} %")
+    print(f"   node steps: {nw} wave-iterations ({nw / it:.2f} per iteration), lanes busy {100.0 * nl / max(1, nw * 64):.1f} %")
+    print(f"   triangle tests: {tw} wave-iterations ({tw / it:.2f} per iteration), lanes busy {100.0 * tl / max(1, tw * 64):.1f} %")
+    sys.exit(0)
 for name, b in (("closest", 0), ("any-hit", 8)):
     calls, pairs, nw, nl, lp, tw, tl, outer = v[b:b + 8]
     if not calls:

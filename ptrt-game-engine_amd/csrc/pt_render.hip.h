@@ -37,9 +37,13 @@ struct PairLds {
     unsigned long long *best; // 64
     uint32_t *occ;            // 64
     uint2 *stack;             // PMODE 2: [entry][lane] BLAS traversal stack
+    // PMODE 2, (lane, triangle) pair compaction of the leaf phase (leaf_pairs)
+    unsigned long long *lkey; // 64: {t bits, index in leaf} min per lane
+    unsigned char *owner;     // 64 * 17 rounded up: lane of each test
 };
+constexpr int LEAF_PAIR_BYTES = 512 + 1152;
 constexpr int PAIR_PAD = 2; // float4 of padding in front of each mesh's packets in LDS (bank spreading)
-PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes) {
+PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_entries = 0) {
     PairLds l;
     char *p = (char *)base;
     l.tris = (float4 *)p;
@@ -49,12 +53,16 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes) {
     l.best = (unsigned long long *)p;
     p += 512;
     l.pairs = (uint32_t *)p;
-    p += (size_t)meshes * 256;
+    p += (size_t)meshes * (stack_entries ? 128 : 256); // PMODE 2 (the only mode with a stack) packs them in 16 bits
     l.ray = (float *)p;
     p += 6 * 256;
     l.occ = (uint32_t *)p;
     p += 256;
     l.stack = (uint2 *)p;
+    p += (size_t)stack_entries * 512;
+    l.lkey = (unsigned long long *)p;
+    p += 512;
+    l.owner = (unsigned char *)p;
     return l;
 }
 
@@ -91,12 +99,17 @@ struct TravStats {
 #define TS_LANE(i)
 #endif
 
+PT_DEV void wave_lds_order() { // LDS is in order within a wave; this only pins the compiler
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 PT_DEV int lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 // step 1: root-box tests + ballot/prefix-sum compaction into the LDS pair list
-template <bool ANY>
+template <bool ANY, bool SHORT = false>
 PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
     const RayO w = make_ray(o, d);
     float tE;
@@ -127,8 +140,12 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
             hb = alive && slab(mh.bmin, mh.bmax, w, ANY ? tMax : T_FAR, tE);
         }
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(hb);
-        if (hb)
-            L.pairs[base + lane_prefix(bal)] = (uint32_t)lane | ((uint32_t)i << 8);
+        if (hb) {
+            if (SHORT)
+                ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)i << 6));
+            else
+                L.pairs[base + lane_prefix(bal)] = (uint32_t)lane | ((uint32_t)i << 8);
+        }
         base += __builtin_popcountll(bal);
     }
     return base;
@@ -262,88 +279,8 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
 // takes one (ray, mesh) pair and walks that mesh's BVH with its own LDS stack, so every lane
 // traverses SOME mesh instead of idling while the wave walks meshes its ray never touches.
 // Within a pair the traversal is the reference's (local best, strict `<`); pairs of one ray
-// merge by the same 64-bit min {t bits, mesh order | payload}.
-PT_DEV Hit closest_hit_pairs_bvh(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
-    const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
-    LdsStack stk{L.stack + lane};
-    __syncthreads();
-    for (int c = 0; c < P; c += 64) {
-        const int p = c + lane;
-        const bool valid = p < P;
-        const uint32_t e = L.pairs[valid ? p : 0];
-        const int r = (int)(e & 63u), oi = (int)(e >> 8);
-        const int4 mt = L.meshtab[oi];
-        f3 po, pd;
-        float dirScale;
-        pair_ray(K, L, r, mt, po, pd, dirScale);
-        const RayO pr = make_ray(po, pd);
-        float tb = T_FAR, ub = 0.0f, vb = 0.0f;
-        int sb = -1;
-        blas_closest<false>(K, mt.x, valid, pr, stk, tb, ub, vb, sb);
-        if (sb >= 0) {
-            const float tw = (mt.z & 1) ? tb / dirScale : tb;
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)oi << 24) | (uint32_t)sb;
-            __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    __syncthreads();
-    const unsigned long long key = L.best[lane];
-    __syncthreads();
-    Hit h;
-    h.u = h.v = 0.0f;
-    if (!alive || key == ~0ull) {
-        h.t = h.t_local = T_FAR;
-        h.mesh = -1;
-        h.slot = -1;
-        return h;
-    }
-    const int4 mt = L.meshtab[(int)((key >> 24) & 0xffu)];
-    h.t = __uint_as_float((uint32_t)(key >> 32));
-    h.mesh = mt.w;
-    h.slot = (int)(key & 0xffffffu);
-    h.t_local = h.t;
-    if (mt.z & 1) {
-        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
-        RayO pr;
-        pr.o = xform_point(rec[2], rec[3], rec[4], o);
-        pr.d = normalize(xform_dir(rec[2], rec[3], rec[4], d));
-        const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
-        float t, u, v;
-        tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, T_FAR, t, u, v);
-        h.t_local = t;
-    }
-    return h;
-}
-
-PT_DEV bool any_hit_pairs_bvh(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
-    const int P = build_pairs<true>(K, L, lane, alive, o, d, tMax);
-    LdsStack stk{L.stack + lane};
-    float *tmaxv = (float *)L.best;
-    tmaxv[lane] = tMax;
-    __syncthreads();
-    for (int c = 0; c < P; c += 64) {
-        const int p = c + lane;
-        const bool valid = p < P;
-        const uint32_t e = L.pairs[valid ? p : 0];
-        const int r = (int)(e & 63u), oi = (int)(e >> 8);
-        const int4 mt = L.meshtab[oi];
-        f3 po, pd;
-        float dirScale;
-        pair_ray(K, L, r, mt, po, pd, dirScale);
-        const RayO pr = make_ray(po, pd);
-        float tm = tmaxv[r];
-        if (mt.z & 1)
-            tm = tm * dirScale;
-        if (blas_any<false>(K, mt.x, valid, pr, tm, stk))
-            L.occ[r] = 1u;
-    }
-    __syncthreads();
-    const bool occluded = alive && (L.occ[lane] != 0u);
-    __syncthreads();
-    return occluded;
-}
-
+// merge by the same 64-bit min {t bits, mesh order | payload}.  Pair entries are 16 bits here
+// ({lane, mesh order < 256}): the list is the second largest LDS user after the stacks.
 // PMODE 2 with dynamic refill.  A batch of 64 pairs runs as long as its LONGEST traversal while the
 // lanes whose pair missed after three nodes idle (measured on the showcase scene: 17 % of the VALU lanes
 // busy).  Here the pair list is a queue: whenever K.fetch_min lanes are idle (or all are), the idle
@@ -351,7 +288,7 @@ PT_DEV bool any_hit_pairs_bvh(const KParams &K, const PairLds &L, int lane, bool
 // their finished pair with the same 64-bit min and start over, while the other lanes keep their
 // traversal state.  Every pair is still traversed exactly as before, so the bits cannot change.
 PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
-    const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
+    const int P = build_pairs<false, true>(K, L, lane, alive, o, d, T_FAR);
     LdsStack stk{L.stack + lane};
     __syncthreads();
     int next = 0;
@@ -381,9 +318,9 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
         if (next < P && (n_idle >= K.fetch_min || n_idle == 64)) {
             const int p = next + lane_prefix(idle);
             if (!busy && p < P) {
-                const uint32_t e = L.pairs[p];
+                const uint32_t e = ((const uint16_t *)L.pairs)[p];
                 r = (int)(e & 63u);
-                oi = (int)(e >> 8);
+                oi = (int)(e >> 6);
                 const int4 mt = L.meshtab[oi];
                 f3 po, pd;
                 pair_ray(K, L, r, mt, po, pd, dirScale);
@@ -419,6 +356,65 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
                 pop();
             }
         }
+        if (K.leaf_pairs) {
+            // Leaf phase as (lane, triangle) pairs.  Lane by lane it runs as long as the largest leaf (<= 17
+            // tests) with the lanes that are not at a leaf idle: 21 % of the lanes busy on the showcase scene.
+            // Instead the tests of all waiting lanes form one list (prefix sum of the leaf sizes), 64 tests
+            // per iteration; a test takes its ray from LDS and merges into its lane with a 64-bit LDS min on
+            // {t bits, index in leaf} = smallest t, then first index: the sequential loop's strict `<`.
+            int cnt = 0, first = 0;
+            if (active) {
+                const int2 lf = K.leaves[~cur];
+                first = lf.x;
+                cnt = lf.y;
+            }
+            int incl = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off)
+                    incl += v;
+            }
+            const int start = incl - cnt;
+            const int T = __builtin_amdgcn_readlane(incl, 63);
+            if (active) {
+                L.lkey[lane] = ~0ull;
+                for (int i = 0; i < cnt; ++i)
+                    L.owner[start + i] = (unsigned char)lane;
+            }
+            wave_lds_order();
+            for (int j0 = 0; j0 < T; j0 += 64) {
+                // everything a test needs of its lane comes out of that lane's registers (ds_bpermute, all
+                // lanes executing), so the list costs LDS only for `owner` and the merge keys
+                const int j = j0 + lane;
+                const int o = L.owner[j < T ? j : 0];
+                const int i = j - __shfl(start, o);
+                const int slot = __shfl(first, o) + i;
+                const float tl = __shfl(tb, o);
+                RayO tr;
+                tr.o = mk3(__shfl(pr.o.x, o), __shfl(pr.o.y, o), __shfl(pr.o.z, o));
+                tr.d = mk3(__shfl(pr.d.x, o), __shfl(pr.d.y, o), __shfl(pr.d.z, o));
+                if (j < T) {
+                    TS_WAVE(5);
+                    TS_LANE(6);
+                    const float4 *tp = K.tris + (size_t)slot * 3;
+                    const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                    float t, u, v;
+                    if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), tr, tl, t, u, v))
+                        __hip_atomic_fetch_min(&L.lkey[o], ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)i,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            wave_lds_order();
+            if (active) {
+                TS_WAVE(4);
+                const unsigned long long key = L.lkey[lane];
+                if (key != ~0ull) {
+                    tb = __uint_as_float((uint32_t)(key >> 32));
+                    sb = first + (int)(uint32_t)key;
+                }
+                pop();
+            }
+        } else
         if (active) { // cur is a leaf
             TS_WAVE(4);
             const int2 lf = K.leaves[~cur];
@@ -492,7 +488,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
 // Any hit, same queue.  A pair whose ray is already known to be occluded is dropped at refill (the
 // answer is an OR over the ray's pairs).
 PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
-    const int P = build_pairs<true>(K, L, lane, alive, o, d, tMax);
+    const int P = build_pairs<true, true>(K, L, lane, alive, o, d, tMax);
     LdsStack stk{L.stack + lane};
     float *tmaxv = (float *)L.best;
     tmaxv[lane] = tMax;
@@ -519,10 +515,10 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
         if (next < P && (n_idle >= K.fetch_min || n_idle == 64)) {
             const int p = next + lane_prefix(idle);
             if (!busy && p < P) {
-                const uint32_t e = L.pairs[p];
+                const uint32_t e = ((const uint16_t *)L.pairs)[p];
                 r = (int)(e & 63u);
                 if (L.occ[r] == 0u) {
-                    const int4 mt = L.meshtab[(int)(e >> 8)];
+                    const int4 mt = L.meshtab[(int)(e >> 6)];
                     f3 po, pd;
                     float dirScale;
                     pair_ray(K, L, r, mt, po, pd, dirScale);
@@ -558,6 +554,57 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
                 pop();
             }
         }
+        if (K.leaf_pairs) { // leaf phase as (lane, triangle) pairs, see closest_hit_pairs_dyn; any hit: a flag per lane
+            int cnt = 0, first = 0;
+            if (busy) {
+                const int2 lf = K.leaves[~cur];
+                first = lf.x;
+                cnt = lf.y;
+            }
+            int incl = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off)
+                    incl += v;
+            }
+            const int start = incl - cnt;
+            const int T = __builtin_amdgcn_readlane(incl, 63);
+            if (busy) {
+                L.lkey[lane] = 0ull;
+                for (int i = 0; i < cnt; ++i)
+                    L.owner[start + i] = (unsigned char)lane;
+            }
+            wave_lds_order();
+            for (int j0 = 0; j0 < T; j0 += 64) {
+                const int j = j0 + lane;
+                const int o = L.owner[j < T ? j : 0];
+                const int i = j - __shfl(start, o);
+                const int slot = __shfl(first, o) + i;
+                const float tl = __shfl(tm, o);
+                RayO tr;
+                tr.o = mk3(__shfl(pr.o.x, o), __shfl(pr.o.y, o), __shfl(pr.o.z, o));
+                tr.d = mk3(__shfl(pr.d.x, o), __shfl(pr.d.y, o), __shfl(pr.d.z, o));
+                if (j < T) {
+                    TS_WAVE(5);
+                    TS_LANE(6);
+                    const float4 *tp = K.tris + (size_t)slot * 3;
+                    const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                    float t, u, v;
+                    if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), tr, tl, t, u, v))
+                        L.lkey[o] = 1ull;
+                }
+            }
+            wave_lds_order();
+            if (busy) {
+                TS_WAVE(4);
+                if (L.lkey[lane] != 0ull) {
+                    L.occ[r] = 1u;
+                    busy = false;
+                } else {
+                    pop();
+                }
+            }
+        } else
         if (busy) { // cur is a leaf
             TS_WAVE(4);
             const int2 lf = K.leaves[~cur];
@@ -603,7 +650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     PairLds PL{};
     if (PMODE) {
         const int staged = (PMODE == 1) ? K.pair_tri_slots : 0;
-        PL = carve_pair_lds((void *)lds_raw, staged, K.pair_meshes);
+        PL = carve_pair_lds((void *)lds_raw, staged, K.pair_meshes, PMODE == 2 ? K.stack_entries : 0);
         const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
         if (PMODE == 1) {
             // mesh i's packets start 2*i float4 (32 B) later than in the arena: with 48-B packets
@@ -704,8 +751,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
 
         // ---- [B] closest hit, all live lanes together
         const Hit h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd)
-                      : (PMODE == 2) ? (K.fetch_min > 0 ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
-                                                        : closest_hit_pairs_bvh(K, PL, lane, live, ro, rd))
+                      : (PMODE == 2) ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
                                      : closest_hit<GEOM>(K, live, ro, rd, stk);
 
         // ---- [C] first half of the shading
@@ -818,8 +864,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         bool in_shadow = false;
         if (__builtin_amdgcn_ballot_w64(want_shadow)) {
             in_shadow = (PMODE == 1)   ? any_hit_pairs(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
-                        : (PMODE == 2) ? (K.fetch_min > 0 ? any_hit_pairs_dyn(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
-                                                          : any_hit_pairs_bvh(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax))
+                        : (PMODE == 2) ? any_hit_pairs_dyn(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
                                        : any_hit<GEOM>(K, want_shadow, shadow_o, L, shadow_tmax, stk);
         }
 

@@ -55,11 +55,6 @@ constexpr uint32_t WF_SPEC = 1u << 16, WF_PREV_SPEC = 1u << 17, WF_EXT = 1u << 1
                    WF_ENDED = 1u << 20, WF_DONE = 1u << 21, WF_PVALID = 1u << 22;
 constexpr int WF_RING = 256; // ring entries per wave (u32): < 64 waiting + at most 128 from one chunk
 
-PT_DEV void wave_lds_order() { // LDS is in order within a wave; this only pins the compiler
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // ---------------------------------------------------------------------------------------------
 // trace: persistent waves, per-lane refill.  Preconditions (checked by the host): single-leaf TLAS
 // with at most 64 meshes, stack_entries >= deepest BLAS.

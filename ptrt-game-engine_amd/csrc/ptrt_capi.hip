@@ -147,7 +147,7 @@ struct ptrt_ctx {
     size_t as_lds = 0;
 
     // options
-    int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16;
+    int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1;
     bool timed = false;
 };
 
@@ -402,7 +402,8 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.pair_meshes = c->pair_meshes;
     K.pair_tri_slots = c->pair_tri_slots;
     K.pair_max_leaf = c->pair_max_leaf;
-    K.fetch_min = c->fetch_min;
+    K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
+    K.leaf_pairs = c->leaf_pairs;
     K.cam = c->cam;
     K.sky_top = c->sky_top;
     K.sky_bottom = c->sky_bottom;
@@ -446,9 +447,9 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
 // in-wave (ray, mesh) pair compaction needs every BLAS to be one leaf and the staged
 // triangle packets to fit a modest LDS budget
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
-    const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * 256 + 6 * 256 + 512 + 256;
+    const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * (pmode == 1 ? 256 : 128) + 6 * 256 + 512 + 256;
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
-                      : common + (size_t)c->stack_entries * 64 * sizeof(uint2);
+                      : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
 }
 // 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
 int pair_mode(const ptrt_ctx *c, int geom) {
@@ -1929,6 +1930,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->force_full = value ? 1 : 0;
     else if (n == "pair_trace") // 0: lock-step mesh loop instead of (ray, mesh) pair compaction (A/B, tests)
         c->pair_trace = value ? 1 : 0;
+    else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
+        c->leaf_pairs = value ? 1 : 0;
     else if (n == "async_lanes") // 1: persistent megakernel with asynchronous lanes for single-leaf-TLAS scenes
         c->async_lanes = value ? 1 : 0;
     else if (n == "shade_min") { // async_lanes: lanes that wait for the shading block before it runs

@@ -16,6 +16,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def P():
+    # torch first: its wheel carries its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Loaded first, that copy
+    # also satisfies libptrt_amd.so's NEEDED entry (same SONAME), so the process has ONE HIP runtime; the other
+    # way round torch loads a second runtime beside /opt/rocm's, and on some boxes the second one then reports
+    # "No HIP GPUs are available" (seen in test_refit / test_build_gpu).  bench.py imports torch first as well.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import ptrt_amd
     return ptrt_amd
 

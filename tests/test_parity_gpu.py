@@ -90,13 +90,15 @@ def test_showcase_small(P, O, blue_noise):
     s.close()
 
 
-@pytest.mark.parametrize("fetch_min", [0, 1, 16, 48, 64])
-def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min):
+@pytest.mark.parametrize("fetch_min,leaf_pairs", [(0, 0), (1, 1), (16, 0), (16, 1), (48, 1), (64, 1)])
+def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs):
     """PMODE 2 (deep BLASes behind a single-leaf TLAS): static 64-pair batches (0) and the dynamic
-    refill at every threshold give the oracle's bits -- showcase materials, plus instanced meshes."""
+    refill at every threshold, with the leaf phase lane by lane (0) or as compacted (lane, triangle)
+    pairs (1), give the oracle's bits -- showcase materials, plus instanced meshes."""
     s = P.Scene(96, 64)
     P.scenes.showcase(s, segments=12)
     s.set_option("fetch_min", fetch_min)
+    s.set_option("leaf_pairs", leaf_pairs)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 5, 2)
     assert_frames_equal(gpu, cpu)
     s.close()
@@ -108,6 +110,7 @@ def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min):
     s.setInstanceScale(extra, (1.5, 0.7, 1.2))
     s.setBVHLeafTarget(2, 0)
     s.set_option("fetch_min", fetch_min)
+    s.set_option("leaf_pairs", leaf_pairs)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
     assert_frames_equal(gpu, cpu)
     s.close()

@@ -336,26 +336,37 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
         }
         if (!__builtin_amdgcn_ballot_w64(busy))
             break;
-        while (active && cur >= 0) {
-            TS_WAVE(2);
-            TS_LANE(3);
-            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
-                         n3 = K.nodes[cur * 4 + 3];
-            float tL, tR;
-            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tb, tL);
-            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tb, tR);
-            const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
-            if (hL || hR) {
-                const bool nearL = hL && (!hR || tL <= tR);
-                if (nearL ? hR : hL) {
-                    stk.push(sp, nearL ? Rr : Lr, nearL ? tR : tL);
-                    ++sp;
+        // Inner nodes.  A lane needs ~2 node steps to its next leaf, the slowest of 64 needs ~12: the
+        // descent stops as soon as K.leaf_min lanes wait at a leaf (wave-uniform loop, predicated step, so
+        // the waiting lanes take part in the ballots); they are served below, pop, and rejoin it.
+        for (;;) {
+            const bool innode = active && cur >= 0;
+            if (!__builtin_amdgcn_ballot_w64(innode))
+                break;
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && cur < 0)) >= K.leaf_min)
+                break;
+            if (innode) {
+                TS_WAVE(2);
+                TS_LANE(3);
+                const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
+                             n3 = K.nodes[cur * 4 + 3];
+                float tL, tR;
+                const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tb, tL);
+                const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tb, tR);
+                const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+                if (hL || hR) {
+                    const bool nearL = hL && (!hR || tL <= tR);
+                    if (nearL ? hR : hL) {
+                        stk.push(sp, nearL ? Rr : Lr, nearL ? tR : tL);
+                        ++sp;
+                    }
+                    cur = nearL ? Lr : Rr;
+                } else {
+                    pop();
                 }
-                cur = nearL ? Lr : Rr;
-            } else {
-                pop();
             }
         }
+        const bool atleaf = active && cur < 0;
         if (K.leaf_pairs) {
             // Leaf phase as (lane, triangle) pairs.  Lane by lane it runs as long as the largest leaf (<= 17
             // tests) with the lanes that are not at a leaf idle: 21 % of the lanes busy on the showcase scene.
@@ -363,7 +374,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
             // per iteration; a test takes its ray from LDS and merges into its lane with a 64-bit LDS min on
             // {t bits, index in leaf} = smallest t, then first index: the sequential loop's strict `<`.
             int cnt = 0, first = 0;
-            if (active) {
+            if (atleaf) {
                 const int2 lf = K.leaves[~cur];
                 first = lf.x;
                 cnt = lf.y;
@@ -376,7 +387,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
             }
             const int start = incl - cnt;
             const int T = __builtin_amdgcn_readlane(incl, 63);
-            if (active) {
+            if (atleaf) {
                 L.lkey[lane] = ~0ull;
                 for (int i = 0; i < cnt; ++i)
                     L.owner[start + i] = (unsigned char)lane;
@@ -405,7 +416,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
                 }
             }
             wave_lds_order();
-            if (active) {
+            if (atleaf) {
                 TS_WAVE(4);
                 const unsigned long long key = L.lkey[lane];
                 if (key != ~0ull) {
@@ -415,7 +426,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
                 pop();
             }
         } else
-        if (active) { // cur is a leaf
+        if (atleaf) { // cur is a leaf
             TS_WAVE(4);
             const int2 lf = K.leaves[~cur];
             const float4 *tp = K.tris + (size_t)lf.x * 3;
@@ -495,13 +506,13 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
     __syncthreads();
     int next = 0;
     bool busy = false;
-    int cur = 0, sp = 0, r = 0;
+    int cur = 0, sp = 0, bot = 0, r = 0; // the lane's stack is entries [bot, sp): thieves take from the bottom
     float tm = 0.0f;
     RayO pr = make_ray(o, d);
     TravStats ts;
     auto pop = [&]() {
         busy = false;
-        if (sp > 0) {
+        if (sp > bot && L.occ[r] == 0u) { // (nothing left to find for a ray some lane has already seen blocked)
             --sp;
             float tE;
             stk.pop(sp, cur, tE);
@@ -527,7 +538,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
                     if (mt.z & 1)
                         tm = tm * dirScale;
                     cur = mt.x;
-                    sp = 0;
+                    sp = bot = 0;
                     busy = true;
                 }
             }
@@ -535,28 +546,83 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
         }
         if (!__builtin_amdgcn_ballot_w64(busy))
             break;
-        while (busy && cur >= 0) {
-            TS_WAVE(2);
-            TS_LANE(3);
-            const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
-                         n3 = K.nodes[cur * 4 + 3];
-            float tL, tR;
-            const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tm, tL);
-            const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tm, tR);
-            const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
-            if (hL && hR) {
-                stk.push(sp, Rr, 0.0f);
-                ++sp;
-                cur = Lr;
-            } else if (hL || hR) {
-                cur = hL ? Lr : Rr;
-            } else {
-                pop();
+        // ---- work stealing.  A wave has ~10 shadow rays (showcase scene) and each walks ~18 nodes one after
+        // the other: 6 % of the lanes busy.  Any-hit is an OR over the subtrees, in any order (E4), so once the
+        // pair queue is empty an idle lane takes the BOTTOM entry of a busy lane's stack -- the largest
+        // subtree that lane still owes -- together with a copy of its ray (ds_bpermute), and walks it with
+        // its own stack.  Stacks only ever lose entries this way, so their depth bound is untouched.
+        bool can_steal = false;
+        if (K.steal && next >= P) {
+            const unsigned long long thieves = __builtin_amdgcn_ballot_w64(!busy);
+            const unsigned long long victims = __builtin_amdgcn_ballot_w64(busy && sp > bot);
+            if (thieves && victims) {
+                const int nt = __builtin_popcountll(thieves), nv = __builtin_popcountll(victims);
+                const int k = nt < nv ? nt : nv;
+                const bool is_victim = busy && sp > bot;
+                const int vrank = lane_prefix(victims), trank = lane_prefix(thieves);
+                if (is_victim && vrank < k)
+                    L.owner[vrank] = (unsigned char)lane;
+                wave_lds_order();
+                const bool steal = !busy && trank < k;
+                const int v = steal ? (int)L.owner[trank] : lane;
+                const int vb = __shfl(bot, v);
+                RayO npr;
+                npr.o = mk3(__shfl(pr.o.x, v), __shfl(pr.o.y, v), __shfl(pr.o.z, v));
+                npr.d = mk3(__shfl(pr.d.x, v), __shfl(pr.d.y, v), __shfl(pr.d.z, v));
+                npr.inv = mk3(__shfl(pr.inv.x, v), __shfl(pr.inv.y, v), __shfl(pr.inv.z, v));
+                const float ntm = __shfl(tm, v);
+                const int nr = __shfl(r, v);
+                if (steal) {
+                    const uint2 e = L.stack[vb * 64 + v];
+                    cur = (int)e.x;
+                    npr.sx = npr.inv.x < 0;
+                    npr.sy = npr.inv.y < 0;
+                    npr.sz = npr.inv.z < 0;
+                    pr = npr;
+                    tm = ntm;
+                    r = nr;
+                    sp = bot = 0;
+                    busy = true;
+                }
+                if (is_victim && vrank < k)
+                    ++bot;
+                wave_lds_order();
+            }
+            can_steal = (thieves != 0ull);
+        }
+        int steps = 0;
+        for (;;) { // inner nodes, see closest_hit_pairs_dyn
+            const bool innode = busy && cur >= 0;
+            if (!__builtin_amdgcn_ballot_w64(innode))
+                break;
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy && cur < 0)) >= K.leaf_min)
+                break;
+            if (can_steal && ++steps > K.steal) // idle lanes are waiting for new stack entries to take
+                break;
+            if (innode) {
+                TS_WAVE(2);
+                TS_LANE(3);
+                const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
+                             n3 = K.nodes[cur * 4 + 3];
+                float tL, tR;
+                const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tm, tL);
+                const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tm, tR);
+                const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+                if (hL && hR) {
+                    stk.push(sp, Rr, 0.0f);
+                    ++sp;
+                    cur = Lr;
+                } else if (hL || hR) {
+                    cur = hL ? Lr : Rr;
+                } else {
+                    pop();
+                }
             }
         }
+        const bool atleaf = busy && cur < 0;
         if (K.leaf_pairs) { // leaf phase as (lane, triangle) pairs, see closest_hit_pairs_dyn; any hit: a flag per lane
             int cnt = 0, first = 0;
-            if (busy) {
+            if (atleaf) {
                 const int2 lf = K.leaves[~cur];
                 first = lf.x;
                 cnt = lf.y;
@@ -569,7 +635,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
             }
             const int start = incl - cnt;
             const int T = __builtin_amdgcn_readlane(incl, 63);
-            if (busy) {
+            if (atleaf) {
                 L.lkey[lane] = 0ull;
                 for (int i = 0; i < cnt; ++i)
                     L.owner[start + i] = (unsigned char)lane;
@@ -595,7 +661,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
                 }
             }
             wave_lds_order();
-            if (busy) {
+            if (atleaf) {
                 TS_WAVE(4);
                 if (L.lkey[lane] != 0ull) {
                     L.occ[r] = 1u;
@@ -605,7 +671,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
                 }
             }
         } else
-        if (busy) { // cur is a leaf
+        if (atleaf) { // cur is a leaf
             TS_WAVE(4);
             const int2 lf = K.leaves[~cur];
             bool found = false;

@@ -141,13 +141,13 @@ struct ptrt_ctx {
     size_t wf_trace_lds = 0;
     int last_mode = 0; // how the last frame was rendered: 0 megakernel, 1 wavefront stages, 2 asynchronous lanes
     // asynchronous-lane megakernel (pt_async.hip.h)
-    int async_lanes = 0, shade_min = 32, leaf_min = 24; // options
+    int async_lanes = 0, shade_min = 32, as_leaf_min = 24; // options
     uint32_t *as_cursor = nullptr;
     int as_blocks[2] = {0, 0}; // resident workgroups of the <false>/<true> kernel at as_lds bytes of LDS
     size_t as_lds = 0;
 
     // options
-    int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1;
+    int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
     bool timed = false;
 };
 
@@ -404,6 +404,8 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.pair_max_leaf = c->pair_max_leaf;
     K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
     K.leaf_pairs = c->leaf_pairs;
+    K.leaf_min = c->leaf_min;
+    K.steal = c->steal;
     K.cam = c->cam;
     K.sky_top = c->sky_top;
     K.sky_bottom = c->sky_bottom;
@@ -561,7 +563,7 @@ int run_async(ptrt_ctx *c, const pt::KParams &K, bool full) {
     A.cursor = c->as_cursor;
     A.n_tiles = K.tiles_x * ((K.rows + 7) / 8);
     A.shade_min = c->shade_min;
-    A.leaf_min = c->leaf_min;
+    A.leaf_min = c->as_leaf_min;
     const int grid = std::min(c->as_blocks[full ? 1 : 0], A.n_tiles);
     HIP_TRY(c, hipMemsetAsync(c->as_cursor, 0, sizeof(uint32_t), c->stream));
     if (full)
@@ -1930,7 +1932,11 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->force_full = value ? 1 : 0;
     else if (n == "pair_trace") // 0: lock-step mesh loop instead of (ray, mesh) pair compaction (A/B, tests)
         c->pair_trace = value ? 1 : 0;
-    else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
+    else if (n == "steal") { // PMODE 2 shadow rays: 0 = no subtree stealing; n = node steps between steal rounds
+        if (value < 0 || value > 64)
+            return fail(c, PTRT_E_INVALID, "steal must be 0..64");
+        c->steal = (int)value;
+    } else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
         c->leaf_pairs = value ? 1 : 0;
     else if (n == "async_lanes") // 1: persistent megakernel with asynchronous lanes for single-leaf-TLAS scenes
         c->async_lanes = value ? 1 : 0;
@@ -1938,10 +1944,10 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         if (value < 1 || value > 64)
             return fail(c, PTRT_E_INVALID, "shade_min must be 1..64");
         c->shade_min = (int)value;
-    } else if (n == "leaf_min") { // async_lanes: lanes waiting at a leaf that end the node loop
+    } else if (n == "leaf_min") { // PMODE 2 and async_lanes: lanes waiting at a leaf that end the node loop
         if (value < 1 || value > 64)
             return fail(c, PTRT_E_INVALID, "leaf_min must be 1..64");
-        c->leaf_min = (int)value;
+        c->leaf_min = c->as_leaf_min = (int)value;
     } else if (n == "wavefront") // 1: trace/shade stages over the whole frame's rays instead of the megakernel
         c->wavefront = value ? 1 : 0;
     else if (n == "fetch_min") { // PMODE 2: refill threshold in idle lanes; 0 = static batches of 64 pairs (A/B, tests)

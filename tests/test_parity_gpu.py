@@ -90,15 +90,19 @@ def test_showcase_small(P, O, blue_noise):
     s.close()
 
 
-@pytest.mark.parametrize("fetch_min,leaf_pairs", [(0, 0), (1, 1), (16, 0), (16, 1), (48, 1), (64, 1)])
-def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs):
+@pytest.mark.parametrize("fetch_min,leaf_pairs,leaf_min,steal", [(0, 0, 64, 0), (1, 1, 1, 1), (16, 0, 8, 2), (16, 1, 8, 0),
+                                                                 (16, 1, 4, 2), (48, 1, 64, 8), (64, 1, 24, 1)])
+def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, leaf_min, steal):
     """PMODE 2 (deep BLASes behind a single-leaf TLAS): static 64-pair batches (0) and the dynamic
     refill at every threshold, with the leaf phase lane by lane (0) or as compacted (lane, triangle)
-    pairs (1), give the oracle's bits -- showcase materials, plus instanced meshes."""
+    pairs (1), the node loop ending once leaf_min lanes wait at a leaf, and idle lanes stealing shadow-ray subtrees (steal > 0),
+    give the oracle's bits -- showcase materials, plus instanced meshes."""
     s = P.Scene(96, 64)
     P.scenes.showcase(s, segments=12)
     s.set_option("fetch_min", fetch_min)
     s.set_option("leaf_pairs", leaf_pairs)
+    s.set_option("leaf_min", leaf_min)
+    s.set_option("steal", steal)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 5, 2)
     assert_frames_equal(gpu, cpu)
     s.close()
@@ -111,6 +115,8 @@ def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs):
     s.setBVHLeafTarget(2, 0)
     s.set_option("fetch_min", fetch_min)
     s.set_option("leaf_pairs", leaf_pairs)
+    s.set_option("leaf_min", leaf_min)
+    s.set_option("steal", steal)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
     assert_frames_equal(gpu, cpu)
     s.close()

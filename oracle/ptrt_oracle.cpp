@@ -3,17 +3,21 @@
  * path-tracing render loop.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this; the product (ptrt-game-engine_amd/) never does.
  *
- * PARITY UNPINNED: the reference (Mark-Rindler/PTRT-game-engine) ships no tests,
- * golden images or known-answer vectors for this path, and it cannot be built in
- * this image (every translation unit needs <cuda_runtime.h> and
- * <curand_kernel.h>, which are absent; writing stand-ins for them is not
- * allowed).  This file is therefore a restatement pinned only by (i) constants
- * and tables that are literal in the reference's source, (ii) the behavioural
- * facts recorded in SURVEY.md (Appendix B), and (iii) for the XORWOW
- * recurrence and its 2^67 jump, rocRAND's independent implementation of the same
- * generator (tests/golden/xorwow_rocrand_kat.json).  cuRAND's seed-scrambling
- * constants are restated from the published algorithm and are NOT verified
- * against a CUDA toolkit.
+ * PARITY UNPINNED except for what oracle/_ref pins: the reference
+ * (Mark-Rindler/PTRT-game-engine) ships no tests, golden images or known-answer
+ * vectors for this path.  Its curand-free headers DO compile in this image
+ * against the real CUDA runtime headers it ships (oracle/ref_probe.cpp ->
+ * oracle/_ref/ref_probe: blue-noise generator, TAA jitter table, Light), and
+ * tests/test_ref_probe.py holds this file's getTAAJitter and the blue-noise
+ * table the renders feed on to that build bit for bit.  Everything else needs
+ * <curand_kernel.h> (absent; writing a stand-in is not allowed) and is a
+ * restatement pinned only by (i) constants and tables that are literal in the
+ * reference's source, (ii) the behavioural facts recorded in SURVEY.md
+ * (Appendix B), and (iii) for the XORWOW recurrence and its 2^67 jump,
+ * rocRAND's independent implementation of the same generator
+ * (tests/golden/xorwow_rocrand_kat.json).  cuRAND's seed-scrambling constants
+ * are restated from the published algorithm and are NOT verified against a
+ * CUDA toolkit.
  *
  * What is restated (reference file:line at each function):
  *   path_trace_kernel   src/pathtracer/scene/scene_kernels.cuh:122-194

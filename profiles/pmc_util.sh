@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage: profiles/pmc_util.sh <tag> <bench args...>   (GPU box, repo root)
 # Lane utilisation and vector-memory pipe counters of the trace kernel, one rocprofv3 --pmc pass per group.
+# (The TA_ADDR_STALLED_BY_TC/TA_DATA_STALLED_BY_TC/TA_ADDR_STALLED_BY_TD group hung rocprofv3 on this pool -- the run was
+# killed after 7 silent minutes -- and is deliberately absent.)
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
@@ -8,7 +10,6 @@ mkdir -p $R/gpurun_out/util_$TAG
 i=0
 for C in "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM" \
          "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
-         "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum" \
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" \
          "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   i=$((i+1))

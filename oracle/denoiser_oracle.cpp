@@ -150,11 +150,31 @@ struct oracle_denoiser_state {
     int32_t *history_object_id;
 };
 
-/* motion_vector_kernel.  cam7 = origin, lower_left_corner, horizontal, vertical (12 floats);
+/* Camera::random_in_unit_disk_hash (camera.cuh:55-72); cosf/sinf -> dm_cos/dm_sin (detmath.h) */
+static V3 random_in_unit_disk_hash(uint32_t x, uint32_t y) {
+    uint32_t seed = (x * 1973u) ^ (y * 9277u) ^ 0x9e3779b9u;
+    seed ^= seed >> 17;
+    seed *= 0xed5ad4bbu;
+    seed ^= seed >> 11;
+    seed *= 0xac4c1b51u;
+    seed ^= seed >> 15;
+    seed *= 0x31848babu;
+    seed ^= seed >> 14;
+    float r1 = ((seed & 0xFFFFu) + 0.5f) / 65536.0f;
+    float r2 = (((seed * 0x343fdu + 0xc0f5u) & 0xFFFFu) + 0.5f) / 65536.0f;
+    float r = sqrtf(r1);
+    float phi = 6.2831853f * r2;
+    return v3(r * dm_cos(phi), r * dm_sin(phi), 0.0f);
+}
+
+/* motion_vector_kernel.  cam19 = origin, lower_left_corner, horizontal, vertical, u, v (18 floats) + lens_radius;
  * prev_view_proj = 16 floats, column-major as mat4 stores them. */
-void oracle_motion_vectors(const float *depth, int W, int H, const float *cam12, const float *pvp, float *out_mv2) {
+void oracle_motion_vectors(const float *depth, int W, int H, const float *cam19, const float *pvp, float *out_mv2) {
+    const float *cam12 = cam19;
     const V3 origin = v3(cam12[0], cam12[1], cam12[2]), llc = v3(cam12[3], cam12[4], cam12[5]),
              hor = v3(cam12[6], cam12[7], cam12[8]), ver = v3(cam12[9], cam12[10], cam12[11]);
+    const V3 cu = v3(cam19[12], cam19[13], cam19[14]), cv = v3(cam19[15], cam19[16], cam19[17]);
+    const float lens_radius = cam19[18];
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             const size_t idx = (size_t)y * W + x;
@@ -165,12 +185,22 @@ void oracle_motion_vectors(const float *depth, int W, int H, const float *cam12,
             }
             float u = (x + 0.5f) / W;
             float v = (y + 0.5f) / H;
-            // cam.get_ray(u, 1-v) with lens_radius <= 0 -> get_ray_simple (camera.cuh:171-205)
+            // cam.get_ray(u, 1-v) (camera.cuh:173-205): lens_radius <= 0 -> get_ray_simple, else the device
+            // branch: a lens sample hashed from (s, t)
             const float s = u, t = 1.0f - v;
+            V3 ray_o = origin;
             V3 rd = llc + hor * s + ver * t - origin;
+            if (lens_radius > 0) {
+                uint32_t hx = (uint32_t)(s * 10000.0f) + (uint32_t)(t * 5000.0f);
+                uint32_t hy = (uint32_t)(t * 10000.0f) + (uint32_t)(s * 5000.0f);
+                V3 disk = random_in_unit_disk_hash(hx, hy) * lens_radius;
+                V3 offset = cu * disk.x + cv * disk.y;
+                rd = llc + hor * s + ver * t - origin - offset;
+                ray_o = origin + offset;
+            }
             float len = sqrtf(dot(rd, rd));
             V3 dir = (len > 0) ? v3(rd.x / len, rd.y / len, rd.z / len) : v3(0.0f);
-            V3 wp = origin + dir * d;
+            V3 wp = ray_o + dir * d;
             // mat4 * vec4, column-major (mat4.cuh:269-274)
             float cx = pvp[0] * wp.x + pvp[4] * wp.y + pvp[8] * wp.z + pvp[12] * 1.0f;
             float cy = pvp[1] * wp.x + pvp[5] * wp.y + pvp[9] * wp.z + pvp[13] * 1.0f;

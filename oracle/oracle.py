@@ -183,11 +183,14 @@ class Denoiser:
 
 
 def motion_vectors(depth, width, height, camera, prev_view_proj):
-    """motion_vector_kernel; `camera` = ptrt_camera-like with origin/lower_left_corner/horizontal/vertical."""
+    """motion_vector_kernel; `camera` = ptrt_camera-like (origin, lower_left_corner, horizontal, vertical, u, v,
+    lens_radius)."""
     cam = np.array([camera.origin.x, camera.origin.y, camera.origin.z,
                     camera.lower_left_corner.x, camera.lower_left_corner.y, camera.lower_left_corner.z,
                     camera.horizontal.x, camera.horizontal.y, camera.horizontal.z,
-                    camera.vertical.x, camera.vertical.y, camera.vertical.z], np.float32)
+                    camera.vertical.x, camera.vertical.y, camera.vertical.z,
+                    camera.u.x, camera.u.y, camera.u.z, camera.v.x, camera.v.y, camera.v.z, camera.lens_radius],
+                   np.float32)
     d = np.ascontiguousarray(depth, np.float32)
     pvp = np.ascontiguousarray(prev_view_proj, np.float32)
     out = np.zeros((width * height, 2), np.float32)

@@ -75,8 +75,9 @@ PT_DEV bool edge_disc(float d0, float d1, f3 n0, f3 n1, int o0, int o1, float dt
 __global__ __launch_bounds__(256) void prep_kernel(float4 *__restrict__ g4, float *__restrict__ out_mv,
                                                    float4 *__restrict__ cur4, const float *__restrict__ accum,
                                                    const float *__restrict__ normal, const float *__restrict__ depth, int W,
-                                                   int H, f3 origin, f3 llc, f3 hor, f3 ver, const float *__restrict__ pvp,
-                                                   int do_motion, float sky, int firefly) {
+                                                   int H, f3 origin, f3 llc, f3 hor, f3 ver, f3 cam_u, f3 cam_v,
+                                                   float lens_radius, const float *__restrict__ pvp, int do_motion,
+                                                   float sky, int firefly) {
     PT_PIXEL_XY
     const float d = depth[idx];
     const f3 n = ld3(normal, idx);
@@ -89,8 +90,30 @@ __global__ __launch_bounds__(256) void prep_kernel(float4 *__restrict__ g4, floa
             const float u = ((float)x + 0.5f) / (float)W;
             const float v = ((float)y + 0.5f) / (float)H;
             const float s = u, t = 1.0f - v;
-            const f3 dir = normalize(llc + hor * s + ver * t - origin);
-            const f3 wp = origin + dir * d;
+            f3 ray_o = origin;
+            f3 rd = llc + hor * s + ver * t - origin;
+            if (lens_radius > 0) { // Camera::get_ray, device branch (camera.cuh:177-185): lens sample hashed from (s, t)
+                const uint32_t hx = (uint32_t)(s * 10000.0f) + (uint32_t)(t * 5000.0f);
+                const uint32_t hy = (uint32_t)(t * 10000.0f) + (uint32_t)(s * 5000.0f);
+                uint32_t seed = (hx * 1973u) ^ (hy * 9277u) ^ 0x9e3779b9u; // random_in_unit_disk_hash (camera.cuh:55-72)
+                seed ^= seed >> 17;
+                seed *= 0xed5ad4bbu;
+                seed ^= seed >> 11;
+                seed *= 0xac4c1b51u;
+                seed ^= seed >> 15;
+                seed *= 0x31848babu;
+                seed ^= seed >> 14;
+                const float r1 = ((float)(seed & 0xFFFFu) + 0.5f) / 65536.0f;
+                const float r2 = ((float)((seed * 0x343fdu + 0xc0f5u) & 0xFFFFu) + 0.5f) / 65536.0f;
+                const float r = __builtin_sqrtf(r1);
+                const float phi = 6.2831853f * r2;
+                const f3 disk = mk3(r * det_cos(phi), r * det_sin(phi), 0.0f) * lens_radius;
+                const f3 offset = cam_u * disk.x + cam_v * disk.y;
+                rd = llc + hor * s + ver * t - origin - offset;
+                ray_o = origin + offset;
+            }
+            const f3 dir = normalize(rd);
+            const f3 wp = ray_o + dir * d;
             const float cx = pvp[0] * wp.x + pvp[4] * wp.y + pvp[8] * wp.z + pvp[12] * 1.0f;
             const float cy = pvp[1] * wp.x + pvp[5] * wp.y + pvp[9] * wp.z + pvp[13] * 1.0f;
             const float cw = pvp[3] * wp.x + pvp[7] * wp.y + pvp[11] * wp.z + pvp[15] * 1.0f;

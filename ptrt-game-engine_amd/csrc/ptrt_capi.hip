@@ -706,8 +706,8 @@ int run_denoiser(ptrt_ctx *c, const pt::KParams &K, unsigned char *rgb8) {
     if (c->mv_active)
         HIP_TRY(c, hipMemcpyAsync(c->dn_pvp, c->prev_view_proj, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pt::prep_kernel, grid, block, 0, c->stream, c->dn_g4[next], c->dn_motion, c->dn_cur4, K.accum,
-                       K.normal, K.depth, W, H, c->cam.origin, c->cam.llc, c->cam.horizontal, c->cam.vertical,
-                       c->dn_pvp, c->mv_active, S.sky_depth_threshold, S.enable_firefly_suppression);
+                       K.normal, K.depth, W, H, c->cam.origin, c->cam.llc, c->cam.horizontal, c->cam.vertical, c->cam.u,
+                       c->cam.v, c->cam.lens_radius, c->dn_pvp, c->mv_active, S.sky_depth_threshold, S.enable_firefly_suppression);
     hipLaunchKernelGGL(pt::temporal_kernel, grid, block, 0, c->stream, c->dn_h1[next], c->dn_h2[next], c->dn_cur4,
                        c->dn_h1[prev], c->dn_h2[prev], c->dn_motion, c->dn_g4[next], c->dn_g4[prev], K.object_id,
                        c->dn_hobj, S, c->dn_first ? 1 : 0, W, H);

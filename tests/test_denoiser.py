@@ -130,3 +130,42 @@ def test_band_contexts_cannot_denoise(P):
     assert P.lib.ptrt_denoiser_enable(s.ctx, None) == -1
     assert b"full-frame" in P.lib.ptrt_last_error(s.ctx)
     s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_thin_lens_camera_motion_vectors_and_frames(P, O, blue_noise):
+    """aperture > 0: the path tracer draws its lens sample from the pixel's random stream (camera.cuh:156-166) and
+    motion_vector_kernel's camera ray takes Camera::get_ray's hashed lens sample (camera.cuh:173-185)."""
+    W, H, spp = 80, 56, 2
+    s = cornell(P, W, H)
+    s.setCamera((0, 0, 5), (0, 0, -5), (0, 1, 0), 40.0, 0.2, 10.0)
+    s.setSamplesPerPixel(spp)
+    s.setMaxBounceDepth(3)
+    s.setDenoiserEnabled(True)
+    s.setBloomEnabled(False)
+    s.initBlueNoise()
+    s.uploadToGPU()
+    rng = O.xorwow_init(P.DEFAULT_SEED, 0, W * H)
+    dn = O.Denoiser(W, H)
+    for f in range(3):
+        if f == 2:
+            s.moveCamera((0.3, 0.1, 5.0))
+        fc = s.getFrameCount()
+        pvp = s.view_proj()
+        s.render_to_host()
+        d = s.flatten()
+        assert d.contents.camera.lens_radius > 0
+        r = O.render(d, W, H, spp, 3, fc, blue_noise, rng, threads=8)
+        assert np.array_equal(s.read(P.BUF_ACCUM).view(np.uint32), r["accum"].view(np.uint32)), f
+        assert np.array_equal(s.read(P.BUF_RNG), rng), f
+        mv = O.motion_vectors(r["depth"], W, H, d.contents.camera, pvp)
+        assert np.array_equal(s.read(P.BUF_MOTION).view(np.uint32), mv.view(np.uint32)), f"motion, frame {f}"
+        den = dn.denoise(r["accum"], r["normal"], r["depth"], mv, r["object_id"])
+        assert np.array_equal(s.read(P.BUF_DENOISED).view(np.uint32), den.view(np.uint32)), f
+    # the lens sample moves the ray origin: vectors differ from the pinhole ones
+    pin = O.motion_vectors(r["depth"], W, H, type("C", (), dict(
+        origin=d.contents.camera.origin, lower_left_corner=d.contents.camera.lower_left_corner,
+        horizontal=d.contents.camera.horizontal, vertical=d.contents.camera.vertical, u=d.contents.camera.u,
+        v=d.contents.camera.v, lens_radius=0.0))(), pvp)
+    assert not np.array_equal(pin, mv)
+    s.close()

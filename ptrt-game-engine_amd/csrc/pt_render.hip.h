@@ -170,8 +170,17 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
     const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
     __syncthreads();
     for (int c = 0; c < P; c += 64) {
-        const int p = c + lane;
-        const bool valid = p < P;
+        // a batch that does not fill the wave (the last one) gives every pair 2^sh lanes, each testing every
+        // 2^sh-th triangle: 18 left-over pairs cost 6 iterations instead of 12.  The lanes of a pair merge
+        // like the pairs of a ray: 64-bit min on {t, mesh order, triangle} = first minimum in leaf order.
+        const int n = (P - c) < 64 ? (P - c) : 64;
+        int sh = 0;
+        // (not with instanced meshes: their key carries t / dirScale, and two local distances that round to
+        // the same world distance must resolve by LOCAL distance first, as one lane's running minimum does)
+        while (K.pair_split && (n << (sh + 1)) <= 64 && (2 << sh) <= K.pair_max_leaf)
+            ++sh;
+        const int p = c + (lane >> sh), sub = lane & ((1 << sh) - 1);
+        const bool valid = (lane >> sh) < n;
         const uint32_t e = L.pairs[valid ? p : 0];
         const int r = (int)(e & 63u), oi = (int)(e >> 8);
         const int4 mt = L.meshtab[oi];
@@ -185,7 +194,9 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
         int bi = -1;
         // (software-pipelining these LDS reads one packet ahead was measured: 2.82 vs 2.75 ms -- with four
         // waves per SIMD the latency is already covered and the extra live registers cost more)
-        for (int i = 0; i < K.pair_max_leaf; ++i) {
+        const int iters = (K.pair_max_leaf + (1 << sh) - 1) >> sh;
+        for (int it = 0; it < iters; ++it) {
+            const int i = sub + (it << sh);
             const int slot = mt.x + (i < mt.y ? i : 0);
             const float4 *tp = L.tris + slot * 3 + oi * PAIR_PAD;
             const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
@@ -242,8 +253,12 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
     tmaxv[lane] = tMax;
     __syncthreads();
     for (int c = 0; c < P; c += 64) {
-        const int p = c + lane;
-        const bool valid = p < P;
+        const int n = (P - c) < 64 ? (P - c) : 64; // 2^sh lanes per pair in a batch that does not fill the wave
+        int sh = 0;
+        while ((n << (sh + 1)) <= 64 && (2 << sh) <= K.pair_max_leaf)
+            ++sh;
+        const int p = c + (lane >> sh), sub = lane & ((1 << sh) - 1);
+        const bool valid = (lane >> sh) < n;
         const uint32_t e = L.pairs[valid ? p : 0];
         const int r = (int)(e & 63u), oi = (int)(e >> 8);
         const int4 mt = L.meshtab[oi];
@@ -257,7 +272,9 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
         if (mt.z & 1)
             tm = tm * dirScale;
         bool found = false;
-        for (int i = 0; i < K.pair_max_leaf; ++i) {
+        const int iters = (K.pair_max_leaf + (1 << sh) - 1) >> sh;
+        for (int it = 0; it < iters; ++it) {
+            const int i = sub + (it << sh);
             const int slot = mt.x + (i < mt.y ? i : 0);
             const float4 *tp = L.tris + slot * 3 + oi * PAIR_PAD;
             const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];

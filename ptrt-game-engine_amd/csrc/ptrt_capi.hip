@@ -139,6 +139,8 @@ struct ptrt_ctx {
     size_t wf_items = 0;
     int wf_trace_blocks = 0;
     size_t wf_trace_lds = 0;
+    bool any_transform = false; // some mesh is an instance with its own transform
+    int pair_split = 1;         // option (A/B, tests)
     int last_mode = 0; // how the last frame was rendered: 0 megakernel, 1 wavefront stages, 2 asynchronous lanes
     // asynchronous-lane megakernel (pt_async.hip.h)
     int async_lanes = 0, shade_min = 32, as_leaf_min = 24; // options
@@ -402,6 +404,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.pair_meshes = c->pair_meshes;
     K.pair_tri_slots = c->pair_tri_slots;
     K.pair_max_leaf = c->pair_max_leaf;
+    K.pair_split = (c->pair_split && !c->any_transform) ? 1 : 0;
     K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
     K.leaf_pairs = c->leaf_pairs;
     K.leaf_min = c->leaf_min;
@@ -1191,6 +1194,9 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     c->tlas_root_ref = troot;
     c->tlas_single_leaf = troot < 0;
     c->all_single_leaf = all_leaf;
+    c->any_transform = false;
+    for (int m = 0; m < mesh_count; ++m)
+        c->any_transform = c->any_transform || meshes[m].has_transform != 0;
     c->stack_entries = R.max_depth < 1 ? 1 : R.max_depth;
     c->pair_tri_slots = (int)(R.tris.size() / 3);
     c->pair_meshes = troot < 0 ? tleaves[~troot].y : 0;
@@ -1938,6 +1944,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->steal = (int)value;
     } else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
         c->leaf_pairs = value ? 1 : 0;
+    else if (n == "pair_split") // PMODE 1: 0 = one lane per pair also in batches that do not fill the wave (A/B, tests)
+        c->pair_split = value ? 1 : 0;
     else if (n == "async_lanes") // 1: persistent megakernel with asynchronous lanes for single-leaf-TLAS scenes
         c->async_lanes = value ? 1 : 0;
     else if (n == "shade_min") { // async_lanes: lanes that wait for the shading block before it runs

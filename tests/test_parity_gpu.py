@@ -73,6 +73,16 @@ def test_cornell_deep_bvh(P, O, blue_noise, leaf):
     s.close()
 
 
+def test_cornell_one_lane_per_pair(P, O, blue_noise):
+    """pair_split=0: partial pair batches keep one lane per pair (the default gives a pair 2^k lanes there)."""
+    s = P.Scene(88, 72)
+    P.scenes.cornell(s)
+    s.set_option("pair_split", 0)
+    gpu, cpu = render_both(P, O, s, blue_noise, 3, 4, 2)
+    assert_frames_equal(gpu, cpu)
+    s.close()
+
+
 def test_cornell_quads(P, O, blue_noise):
     s = P.Scene(64, 64)
     P.scenes.cornell(s, quads=True)

@@ -43,6 +43,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     const int lane = threadIdx.x;
     LdsStack stk{lds_raw + lane};
     uint32_t *ring = (uint32_t *)(lds_raw + K.stack_entries * 64);
+    unsigned long long *lkey = (unsigned long long *)(ring + AS_RING); // 64 merge keys of the leaf phase
+    unsigned char *owner = (unsigned char *)(lkey + 64);               // 64 * 17 rounded up: lane of each test
     int ring_head = 0, ring_n = 0; // wave-uniform
     bool pool_empty = false;
     const int2 tl = K.tlas_leaves[~K.tlas_root_ref];
@@ -474,41 +476,72 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
                 }
             }
         }
-        // ---- leaf
-        if (active && cur < 0) {
-            const int2 lf = K.leaves[~cur];
-            const float4 *tp = K.tris + (size_t)lf.x * 3;
-            float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-            if (lf.y > 0) {
-                p0 = tp[0];
-                p1 = tp[1];
-                p2 = tp[2];
-            }
-            for (int i = 0; i < lf.y; ++i) {
+        // ---- leaf phase as (lane, triangle) pairs (see closest_hit_pairs_dyn in pt_render.hip.h): the tests of all
+        // lanes waiting at a leaf form one list, 64 per iteration; ray, limit and leaf start come out of the
+        // owner lane's registers (ds_bpermute); merge by LDS 64-bit min {t bits, index} -- or a flag for shadow rays
+        {
+            const bool atleaf = active && cur < 0;
+            if (__builtin_amdgcn_ballot_w64(atleaf)) {
+                int cnt = 0, first = 0;
+                if (atleaf) {
+                    const int2 lf = K.leaves[~cur];
+                    first = lf.x;
+                    cnt = lf.y;
+                }
+                int incl = cnt;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(incl, off);
+                    if (lane >= off)
+                        incl += v;
+                }
+                const int start = incl - cnt;
+                const int T = __builtin_amdgcn_readlane(incl, 63);
+                if (atleaf) {
+                    lkey[lane] = ~0ull;
+                    for (int i = 0; i < cnt; ++i)
+                        owner[start + i] = (unsigned char)lane;
+                }
+                wave_lds_order();
+                for (int j0 = 0; j0 < T; j0 += 64) {
+                    const int j = j0 + lane;
+                    const int o = owner[j < T ? j : 0];
+                    const int i = j - __shfl(start, o);
+                    const int slot = __shfl(first, o) + i;
+                    const float tl = __shfl(tb, o);
+                    RayO tr;
+                    tr.o = mk3(__shfl(pr.o.x, o), __shfl(pr.o.y, o), __shfl(pr.o.z, o));
+                    tr.d = mk3(__shfl(pr.d.x, o), __shfl(pr.d.y, o), __shfl(pr.d.z, o));
+                    if (j < T) {
 #ifdef PT_TRAV_STATS
-                if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
-                    ++ts2[0];
-                ++ts2[1];
+                        if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                            ++ts2[0];
+                        ++ts2[1];
 #endif
-                const int nx = (i + 1 < lf.y) ? (i + 1) : i;
-                const float4 q0 = tp[nx * 3 + 0], q1 = tp[nx * 3 + 1], q2 = tp[nx * 3 + 2];
-                float t, u, v;
-                if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tb, t, u, v)) {
-                    if (anyq) {
-                        found = true;
-                    } else {
-                        tb = t;
-                        sb = lf.x + i;
+                        const float4 *tp = K.tris + (size_t)slot * 3;
+                        const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                        float t, u, v;
+                        if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), tr, tl, t, u, v))
+                            __hip_atomic_fetch_min(&lkey[o], ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)i,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                p0 = q0;
-                p1 = q1;
-                p2 = q2;
+                wave_lds_order();
+                if (atleaf) {
+                    const unsigned long long key = lkey[lane];
+                    if (key != ~0ull) {
+                        if (anyq) {
+                            found = true;
+                        } else {
+                            tb = __uint_as_float((uint32_t)(key >> 32));
+                            sb = first + (int)(uint32_t)key;
+                        }
+                    }
+                    if (found)
+                        active = false;
+                    else
+                        pop();
+                }
             }
-            if (found)
-                active = false;
-            else
-                pop();
         }
     }
 

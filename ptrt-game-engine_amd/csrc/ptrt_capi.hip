@@ -541,11 +541,11 @@ int run_wavefront(ptrt_ctx *c, const pt::KParams &K, bool full, int spp, int max
 bool async_applicable(const ptrt_ctx *c) {
     if (!c->async_lanes || !c->tlas_single_leaf || c->pair_meshes <= 0 || c->pair_meshes > 64)
         return false;
-    return ((size_t)c->stack_entries * 64 + pt::AS_RING / 2) * sizeof(uint2) <= 40 * 1024;
+    return ((size_t)c->stack_entries * 64 + pt::AS_RING / 2) * sizeof(uint2) + pt::LEAF_PAIR_BYTES <= 40 * 1024;
 }
 
 int run_async(ptrt_ctx *c, const pt::KParams &K, bool full) {
-    const size_t lds = ((size_t)c->stack_entries * 64 + pt::AS_RING / 2) * sizeof(uint2);
+    const size_t lds = ((size_t)c->stack_entries * 64 + pt::AS_RING / 2) * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
     if (!c->as_cursor)
         HIP_TRY(c, hipMalloc((void **)&c->as_cursor, sizeof(uint32_t)));
     if (c->as_lds != lds || !c->as_blocks[full ? 1 : 0]) {

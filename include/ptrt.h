@@ -366,7 +366,15 @@ int ptrt_trace_rays(ptrt_ctx *ctx, const float *origins, const float *directions
  * only maintained when ptrt_set_option(ctx,"count_rays",1). */
 int ptrt_get_stats(ptrt_ctx *ctx, ptrt_stats *out);
 
-/* tuning / diagnostics knobs, by name; unknown names return PTRT_E_INVALID */
+/* tuning / diagnostics knobs, by name; unknown names return PTRT_E_INVALID.  None changes a bit of
+ * any output (tests force every value and compare with the oracle):
+ *   count_rays 0|1        maintain the ptrt_get_stats counters
+ *   force_geom -1..2      force a more general traversal variant       force_full 0|1  all material branches
+ *   pair_trace 0|1        (ray, mesh) pair compaction                  pair_split 0|1  lanes per pair in partial batches
+ *   fetch_min 0..64       idle lanes before the pair queue refills     leaf_pairs 0|1  compacted leaf phase
+ *   leaf_min 1..64        lanes waiting at a leaf that end the descent steal 0..64     shadow-ray subtree stealing
+ *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9
+ *   denoiser_active, motion_vectors, use_graphs 0|1 */
 int ptrt_set_option(ptrt_ctx *ctx, const char *name, long long value);
 
 /* Render on a caller-owned HIP stream (a `hipStream_t` passed as void*; NULL returns to the

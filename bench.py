@@ -117,6 +117,7 @@ def main():
     scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, dev_index)
     scene.setSamplesPerPixel(args.spp)
     scene.setMaxBounceDepth(args.depth)
+    post_on_rank0 = world > 1 and (args.denoise or args.bloom)
     if world == 1:
         scene.setDenoiserEnabled(args.denoise)
         scene.setBloomEnabled(args.bloom)
@@ -140,6 +141,29 @@ def main():
         views = [tilefarm.frame_views(f, H, world) for f in frames]
     pending = [None, None]
 
+    # --denoise / --bloom with N > 1 (not the headline): the bands send HDR + G-buffers (32 B/px) instead of RGB8 and
+    # rank 0 runs the post chain over the gathered frame in a second, full-frame context (tilefarm.gather_gbuffers,
+    # Scene.post_frame -> ptrt_post_frame)
+    presenter = gviews = gframe = gband = out_frame = None
+    if post_on_rank0:
+        kinds = dict(accum=P.BUF_ACCUM, normal=P.BUF_NORMAL, depth=P.BUF_DEPTH, object_id=P.BUF_OBJECT_ID)
+        gband = {k: torch.as_tensor(scene.device_array(kind), device="cuda") for k, kind in kinds.items()}
+        if rehearse:
+            gband_host = None
+        if rank == 0:
+            presenter = build_scene(P, args.scene, W, H, 0, 0, dev_index)
+            presenter.setSamplesPerPixel(args.spp)
+            presenter.setMaxBounceDepth(args.depth)
+            presenter.setDenoiserEnabled(args.denoise)
+            presenter.setBloomEnabled(args.bloom)
+            presenter.initBlueNoise()
+            presenter.uploadToGPU()
+            presenter.set_stream(stream.cuda_stream)
+            dev = "cpu" if rehearse else "cuda"
+            gframe = {k: torch.empty((H * W, c), dtype=getattr(torch, dt), device=dev) for k, c, dt in tilefarm.GBUFFER_KINDS}
+            gviews = tilefarm.gbuffer_views(gframe, H, world)
+            out_frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+
     # config 5 ("fluid"): every step first moves the water surface (new vertex positions already in
     # HBM), refits the BVH on the GPU, then traces: the refit+trace pipeline, no host sync inside
     water = None
@@ -159,6 +183,14 @@ def main():
         if pending[b] is not None:
             pending[b].wait()
         scene.render_to_device(tiles[b].data_ptr())
+        if post_on_rank0:
+            src = {k: (t.cpu() if rehearse else t) for k, t in gband.items()}
+            tilefarm.gather_gbuffers(dist, src, gviews, rank, world, H)
+            if rank == 0:
+                fr = {k: (t.cuda() if rehearse else t) for k, t in gframe.items()}
+                presenter.post_frame(fr["accum"].data_ptr(), fr["normal"].data_ptr(), fr["depth"].data_ptr(),
+                                     fr["object_id"].data_ptr(), out_frame.data_ptr())
+            return
         if rehearse:
             tilefarm.gather_bands(dist, tiles[b].cpu(), views[b], rank, world, H)
         else:
@@ -227,7 +259,7 @@ def main():
                                + (f" scale{args.scale}" if args.scale != 1.0 else "")
                                + (" +gpu-rebuild" if args.rebuild else ""), "scene": args.scene,
                    "width": W, "height": H, "spp": args.spp, "max_depth": args.depth,
-                   "parallelism": f"tile{world}" if world > 1 else "single",
+                   "parallelism": (f"tile{world}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
                    "kernel": "path_trace_kernel (megakernel, fused tonemap)"},
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -366,6 +366,16 @@ int ptrt_trace_rays(ptrt_ctx *ctx, const float *origins, const float *directions
  * only maintained when ptrt_set_option(ctx,"count_rays",1). */
 int ptrt_get_stats(ptrt_ctx *ctx, ptrt_stats *out);
 
+/* Tile farm, presenting rank: steps 3-7 of Scene::render_to_device (motion vectors,
+ * Denoiser::denoise, bloom, tonemap; scene.cuh:1103-1208) of a FULL-FRAME context over a frame whose
+ * HDR image and G-buffers were rendered by other contexts (bands) and gathered into DEVICE memory:
+ * accum/normal width*height*3 floats, depth width*height floats, object_id width*height ints, top-down,
+ * i.e. the bands' ptrt_device_buffer contents concatenated in row order.  Camera, previous view-projection
+ * and the denoiser/bloom switches are the context's own.  PTRT_E_INVALID for a band context, a reduced
+ * render size, or when neither stage is enabled. */
+int ptrt_post_frame(ptrt_ctx *ctx, const float *accum, const float *normal, const float *depth,
+                    const int32_t *object_id, void *out_rgb8, int out_is_device);
+
 /* tuning / diagnostics knobs, by name; unknown names return PTRT_E_INVALID.  None changes a bit of
  * any output (tests force every value and compare with the oracle):
  *   count_rays 0|1        maintain the ptrt_get_stats counters

@@ -1648,6 +1648,48 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     return PTRT_OK;
 }
 
+// Presenting rank of the tile farm: steps 3-7 of Scene::render_to_device (motion vectors,
+// denoiser, bloom, tonemap; scene.cuh:1103-1208) of a FULL-FRAME context over a frame whose HDR image and
+// G-buffers were rendered elsewhere -- the band contexts -- and gathered into device memory.
+int ptrt_post_frame(ptrt_ctx *c, const float *accum, const float *normal, const float *depth, const int32_t *object_id,
+                    void *out_rgb8, int out_is_device) {
+    if (!ctx_live(c) || !accum || !normal || !depth || !object_id)
+        return fail(c, PTRT_E_INVALID, "ptrt_post_frame: bad argument");
+    if (c->rows != c->H || c->y0 != 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_post_frame: needs a full-frame context (this one holds rows %d..%d of %d)", c->y0,
+                    c->y0 + c->rows, c->H);
+    if (c->scaled())
+        return fail(c, PTRT_E_INVALID, "ptrt_post_frame: the frame must have the context's size (render size %dx%d != %dx%d)",
+                    c->rw, c->rh, c->W, c->H);
+    const bool denoise = c->dn_on && c->dn_active, bloom = c->bloom_on != 0;
+    if (!denoise && !bloom)
+        return fail(c, PTRT_E_INVALID, "ptrt_post_frame: neither denoiser nor bloom is enabled (gather the RGB8 bands instead)");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_accum, accum, c->npix * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_normal, normal, c->npix * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_depth, depth, c->npix * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_object_id, object_id, c->npix * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    pt::KParams K = make_params(c);
+    unsigned char *frame_rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
+    c->last_rgb8 = frame_rgb8;
+    float *current = K.accum;
+    if (denoise) {
+        if (int rc = run_denoiser(c, K, bloom ? nullptr : frame_rgb8))
+            return rc;
+        current = c->dn_out;
+    }
+    if (bloom) {
+        if (int rc = run_bloom(c, current, c->rw, c->rh, frame_rgb8))
+            return rc;
+    }
+    if (out_rgb8 && !out_is_device) {
+        HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PTRT_OK;
+}
+
 int ptrt_sync(ptrt_ctx *c) {
     if (!ctx_live(c))
         return fail(c, PTRT_E_INVALID, "ptrt_sync: bad context");

@@ -271,6 +271,12 @@ int hs_render_to_host(void *s, void *host_pixels) {
     HS_TRY(static_cast<Scene *>(s)->render_to_host(static_cast<unsigned char *>(host_pixels)));
     return 0;
 }
+int hs_post_frame(void *s, const float *accum, const float *normal, const float *depth, const int *object_id,
+                  void *pixels, int is_device) {
+    HS_TRY(static_cast<Scene *>(s)->postFrameFromDevice(accum, normal, depth, object_id,
+                                                        static_cast<unsigned char *>(pixels), is_device));
+    return 0;
+}
 int hs_get_frame_count(void *s) { return static_cast<Scene *>(s)->getFrameCount(); }
 void hs_set_frame_count(void *s, int f) { static_cast<Scene *>(s)->setFrameCount(f); }
 int hs_trace_single_ray(void *s, const float *o3, const float *d3, ptrt_hit *out) {

@@ -629,6 +629,31 @@ class Scene {
     // its PT Scene -- callers there map a GL buffer instead
     void render_to_host(unsigned char *host_pixels) { renderInternal(host_pixels, 0); }
 
+    // Tile farm, presenting rank: the post chain of render_to_device over a frame gathered from band contexts
+    // (device pointers, top-down; include/ptrt.h ptrt_post_frame).  Same bookkeeping as a rendered frame.
+    void postFrameFromDevice(const float *accum, const float *normal, const float *depth, const int *object_id,
+                             unsigned char *pixels, int is_device) {
+        const bool denoise = perfSettings.enableDenoiser && denoiserAllocated;
+        const bool bloom = perfSettings.enableBloom && fullFrame && render_width >= 64 && render_height >= 64;
+        if (fullFrame)
+            check(ptrt_set_bloom(ctx, bloom ? 1 : 0), "bloom");
+        if (denoiserAllocated) {
+            check(ptrt_set_option(ctx, "denoiser_active", denoise ? 1 : 0), "denoiser option");
+            check(ptrt_set_option(ctx, "motion_vectors", (denoise && perfSettings.enableMotionVectors) ? 1 : 0),
+                  "denoiser option");
+            check(ptrt_set_prev_view_proj(ctx, prev_view_proj.m), "prev view-proj");
+        }
+        if (cameraDirty) {
+            ptrt_camera c = camera.flat();
+            check(ptrt_set_camera(ctx, &c), "Failed to set camera");
+            cameraDirty = false;
+        }
+        check(ptrt_post_frame(ctx, accum, normal, depth, object_id, pixels, is_device), "ptrt_post_frame");
+        frame_count_++;
+        prev_view_proj = camera.get_view_proj();
+    }
+
+
     HitInfo traceSingleRay(const vec3 &o, const vec3 &d) { // scene.cuh:1367-1391
         HitInfo h;
         needBackend();

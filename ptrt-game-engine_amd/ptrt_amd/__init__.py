@@ -204,6 +204,7 @@ _sig("hs_update_triangles", C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int)
 _sig("hs_mesh_prim_indices", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.c_int)
 _sig("hs_render_to_device", C.c_int, _vp, _vp)
 _sig("hs_render_to_host", C.c_int, _vp, _vp)
+_sig("hs_post_frame", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int)
 _sig("hs_get_frame_count", C.c_int, _vp)
 _sig("hs_set_frame_count", None, _vp, C.c_int)
 _sig("hs_trace_single_ray", C.c_int, _vp, _fp, _fp, C.POINTER(Hit))
@@ -437,6 +438,17 @@ class Scene:
         self._chk(lib.hs_render_to_host(self._h, out.ctypes.data_as(_vp)))
         return out
 
+    def post_frame(self, accum_ptr, normal_ptr, depth_ptr, object_id_ptr, out_device_ptr=None):
+        """Presenting rank of the tile farm: motion vectors + denoiser + bloom + tonemap of this full-frame scene
+        over a gathered frame (device pointers, top-down; `ptrt_post_frame`).  RGB8 goes to `out_device_ptr`, or is
+        returned as a host array."""
+        if out_device_ptr is not None:
+            self._chk(lib.hs_post_frame(self._h, accum_ptr, normal_ptr, depth_ptr, object_id_ptr, C.c_void_p(out_device_ptr), 1))
+            return None
+        out = np.empty((self.tile_rows, self.width, 3), dtype=np.uint8)
+        self._chk(lib.hs_post_frame(self._h, accum_ptr, normal_ptr, depth_ptr, object_id_ptr, out.ctypes.data_as(_vp), 0))
+        return out
+
     def view_run(self, frames, slots=2, keep=True, dump_prefix="", dump_every=0):
         """The reference's viewer loop (map_pbo -> render_to_device -> unmap -> blit -> draw) over the HIP
         presentation ring, headless.  Returns (frames as uint8 (n, H, W, 3) or None, wall ms per frame)."""
@@ -447,6 +459,20 @@ class Scene:
         return out, ms.value
 
     def sync(self): self._cchk(lib.ptrt_sync(self.ctx))
+
+    def device_array(self, kind):
+        """Zero-copy view of a frame buffer in device memory for array libraries that accept
+        `__cuda_array_interface__` (e.g. `torch.as_tensor(scene.device_array(P.BUF_ACCUM), device="cuda")`)."""
+        n = self.tile_rows * self.width
+        shape, typestr = {BUF_ACCUM: ((n, 3), "<f4"), BUF_NORMAL: ((n, 3), "<f4"), BUF_DEPTH: ((n, 1), "<f4"),
+                          BUF_OBJECT_ID: ((n, 1), "<i4")}[kind]
+        ptr = lib.ptrt_device_buffer(self.ctx, kind)
+        if not ptr:
+            raise PtrtError(lib.ptrt_last_error(self.ctx).decode())
+
+        class _View:
+            __cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        return _View()
 
     def read(self, kind):
         n = self.tile_rows * self.width

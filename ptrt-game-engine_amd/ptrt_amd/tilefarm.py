@@ -56,3 +56,44 @@ def gather_bands(dist, tile, views, rank, world, height, async_op=False):
     for q in reqs:
         q.wait()
     return None
+
+
+# ---- denoiser / bloom on the presenting rank -------------------------------------------------------
+# The spatiotemporal denoiser reads +-32 rows around a pixel (a-trous step 16) and previous-frame history, bloom
+# a six-level mip chain of the whole frame: both run where the whole frame is.  The bands therefore send their HDR
+# image and G-buffers instead of RGB8 -- accum 12 + normal 12 + depth 4 + objectId 4 = 32 B/px, 8.3 MB per rank at
+# 1080p / 8 GPUs, still ~60 us per link on xGMI -- and rank 0 runs `Scene.post_frame` (ptrt_post_frame) over them.
+# HDR and G-buffers are top-down, so the gathered frame is the plain concatenation of the bands in rank order.
+GBUFFER_KINDS = (("accum", 3, "float32"), ("normal", 3, "float32"), ("depth", 1, "float32"), ("object_id", 1, "int32"))
+
+
+def gbuffer_views(frames, height, world):
+    """frames: dict kind -> (H*W, c) tensor on rank 0; returns per kind the list of per-rank row-range views."""
+    out = {}
+    for kind, _, _ in GBUFFER_KINDS:
+        t = frames[kind]
+        w = t.shape[0] // height
+        out[kind] = [t[y0 * w:(y0 + rows) * w] for (y0, rows) in bands(height, world)]
+    return out
+
+
+def gather_gbuffers(dist, band, views, rank, world, height, async_op=False):
+    """Collective: every rank contributes its band's four buffers (dict kind -> (rows*W, c) tensor); rank 0
+    receives them into `views` (from gbuffer_views).  Returns None or an object with .wait()."""
+    if world == 1:
+        return None
+    works = []
+    for kind, _, _ in GBUFFER_KINDS:
+        if height % world == 0:
+            works.append(dist.gather(band[kind], views[kind] if rank == 0 else None, dst=0, async_op=async_op))
+        elif rank == 0:
+            views[kind][0].copy_(band[kind])
+            works += [dist.irecv(views[kind][r], src=r) for r in range(1, world)]
+        else:
+            works.append(dist.isend(band[kind], dst=0))
+    if async_op:
+        return _Works(works)
+    for w in works:
+        if w is not None and hasattr(w, "wait"):
+            w.wait()
+    return None

@@ -70,6 +70,8 @@ struct KParams {
     int pair_meshes;    // meshes in the (single) TLAS leaf
     int pair_tri_slots; // triangle packets staged in LDS (all leaf slots, 0..n)
     int pair_max_leaf;  // largest leaf
+    int tlas_max_leaf;  // PMODE 3: most meshes in one TLAS leaf
+    int tlas_depth;     // PMODE 3: TLAS stack entries per lane
     int pair_split;     // PMODE 1: a batch that does not fill the wave may give each pair several lanes
     int steal;          // PMODE 2 any-hit: 0 off; n > 0: idle lanes steal subtrees, node loop yields every n steps
     int leaf_min;       // PMODE 2: lanes waiting at a leaf that end the node loop (64 = all of them)

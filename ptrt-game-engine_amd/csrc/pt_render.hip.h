@@ -38,12 +38,15 @@ struct PairLds {
     uint32_t *occ;            // 64
     uint2 *stack;             // PMODE 2: [entry][lane] BLAS traversal stack
     // PMODE 2, (lane, triangle) pair compaction of the leaf phase (leaf_pairs)
+    int *leafx;               // PMODE 3: 64: first TLAS index of the leaf each ray is at
+    uint2 *tstack;            // PMODE 3: [entry][lane] TLAS traversal stack
     unsigned long long *lkey; // 64: {t bits, index in leaf} min per lane
     unsigned char *owner;     // 64 * 17 rounded up: lane of each test
 };
 constexpr int LEAF_PAIR_BYTES = 512 + 1152;
 constexpr int PAIR_PAD = 2; // float4 of padding in front of each mesh's packets in LDS (bank spreading)
-PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_entries = 0) {
+PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_entries = 0, int tlas_leaf = 0,
+                              int tlas_depth = 0) {
     PairLds l;
     char *p = (char *)base;
     l.tris = (float4 *)p;
@@ -53,13 +56,18 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     l.best = (unsigned long long *)p;
     p += 512;
     l.pairs = (uint32_t *)p;
-    p += (size_t)meshes * (stack_entries ? 128 : 256); // PMODE 2 (the only mode with a stack) packs them in 16 bits
+    // PMODE 2 and 3 (the modes with a stack) pack them in 16 bits; PMODE 3 holds one TLAS leaf per ray at a time
+    p += tlas_leaf ? (size_t)tlas_leaf * 128 : (size_t)meshes * (stack_entries ? 128 : 256);
     l.ray = (float *)p;
     p += 6 * 256;
     l.occ = (uint32_t *)p;
     p += 256;
     l.stack = (uint2 *)p;
     p += (size_t)stack_entries * 512;
+    l.tstack = (uint2 *)p;
+    p += (size_t)tlas_depth * 512;
+    l.leafx = (int *)p;
+    p += tlas_leaf ? 256 : 0;
     l.lkey = (unsigned long long *)p;
     p += 512;
     l.owner = (unsigned char *)p;
@@ -304,15 +312,24 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
 // lanes take the next pairs -- rank by ballot/mbcnt, `next` is wave-uniform, no atomics -- commit
 // their finished pair with the same 64-bit min and start over, while the other lanes keep their
 // traversal state.  Every pair is still traversed exactly as before, so the bits cannot change.
-PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
-    const int P = build_pairs<false, true>(K, L, lane, alive, o, d, T_FAR);
+// mesh of a pair entry.  GEN = false: `order` indexes the single TLAS leaf (L.meshtab).  GEN = true (general TLAS,
+// PMODE 3): `order` indexes the TLAS leaf the RAY is currently at (L.leafx[r]), the head comes from the mesh records.
+template <bool GEN> PT_DEV int4 pair_mesh(const KParams &K, const PairLds &L, int r, int order) {
+    if (!GEN)
+        return L.meshtab[order];
+    const int m = K.tlas_mesh_ids[L.leafx[r] + order];
+    const MeshHead mh = load_mesh_head(K, m);
+    return make_int4(mh.root_ref, 0, mh.flags, m);
+}
+
+// drains the pair queue [0, P): afterwards L.best[r] = min over ray r's pairs of {t bits, order << 24 | slot}
+template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P) {
     LdsStack stk{L.stack + lane};
-    __syncthreads();
     int next = 0;
     bool busy = false, active = false, xf = false;
     int cur = 0, sp = 0, r = 0, oi = 0, sb = -1;
     float dirScale = 1.0f, tb = T_FAR;
-    RayO pr = make_ray(o, d);
+    RayO pr = make_ray(mk3(0.0f), mk3(0.0f, 0.0f, 1.0f));
     TravStats ts;
     auto pop = [&]() {
         active = false;
@@ -338,7 +355,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
                 const uint32_t e = ((const uint16_t *)L.pairs)[p];
                 r = (int)(e & 63u);
                 oi = (int)(e >> 6);
-                const int4 mt = L.meshtab[oi];
+                const int4 mt = pair_mesh<GEN>(K, L, r, oi);
                 f3 po, pd;
                 pair_ray(K, L, r, mt, po, pd, dirScale);
                 pr = make_ray(po, pd);
@@ -484,6 +501,24 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
     ts.v[1] = lane == 0 ? (unsigned)P : 0u;
 #endif
     ts.flush(0, lane);
+}
+
+// local-space distance of the winner in an instanced mesh, needed for localPoint (intersection.cuh:382,466)
+PT_DEV float winner_t_local(const KParams &K, int mesh, int slot, f3 o, f3 d) {
+    const float4 *rec = K.mesh_recs + mesh * MESH_REC_F4;
+    RayO lr;
+    lr.o = xform_point(rec[2], rec[3], rec[4], o);
+    lr.d = normalize(xform_dir(rec[2], rec[3], rec[4], d));
+    const float4 p0 = K.tris[slot * 3 + 0], p1 = K.tris[slot * 3 + 1], p2 = K.tris[slot * 3 + 2];
+    float t, u, v;
+    tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), lr, T_FAR, t, u, v);
+    return t;
+}
+
+PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
+    const int P = build_pairs<false, true>(K, L, lane, alive, o, d, T_FAR);
+    __syncthreads();
+    run_closest_queue<false>(K, L, lane, P);
     __syncthreads();
     const unsigned long long key = L.best[lane];
     __syncthreads();
@@ -500,32 +535,22 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
     h.mesh = mt.w;
     h.slot = (int)(key & 0xffffffu);
     h.t_local = h.t;
-    if (mt.z & 1) {
-        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
-        RayO lr;
-        lr.o = xform_point(rec[2], rec[3], rec[4], o);
-        lr.d = normalize(xform_dir(rec[2], rec[3], rec[4], d));
-        const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
-        float t, u, v;
-        tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), lr, T_FAR, t, u, v);
-        h.t_local = t;
-    }
+    if (mt.z & 1)
+        h.t_local = winner_t_local(K, h.mesh, h.slot, o, d);
     return h;
 }
 
 // Any hit, same queue.  A pair whose ray is already known to be occluded is dropped at refill (the
 // answer is an OR over the ray's pairs).
-PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
-    const int P = build_pairs<true, true>(K, L, lane, alive, o, d, tMax);
+// drains the pair queue [0, P): afterwards L.occ[r] != 0 for every ray r one of whose pairs found a hit
+template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L, int lane, int P) {
     LdsStack stk{L.stack + lane};
-    float *tmaxv = (float *)L.best;
-    tmaxv[lane] = tMax;
-    __syncthreads();
+    const float *tmaxv = (const float *)L.best;
     int next = 0;
     bool busy = false;
     int cur = 0, sp = 0, bot = 0, r = 0; // the lane's stack is entries [bot, sp): thieves take from the bottom
     float tm = 0.0f;
-    RayO pr = make_ray(o, d);
+    RayO pr = make_ray(mk3(0.0f), mk3(0.0f, 0.0f, 1.0f));
     TravStats ts;
     auto pop = [&]() {
         busy = false;
@@ -546,7 +571,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
                 const uint32_t e = ((const uint16_t *)L.pairs)[p];
                 r = (int)(e & 63u);
                 if (L.occ[r] == 0u) {
-                    const int4 mt = L.meshtab[(int)(e >> 6)];
+                    const int4 mt = pair_mesh<GEN>(K, L, r, (int)(e >> 6));
                     f3 po, pd;
                     float dirScale;
                     pair_ray(K, L, r, mt, po, pd, dirScale);
@@ -713,10 +738,202 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
     ts.v[1] = lane == 0 ? (unsigned)P : 0u;
 #endif
     ts.flush(8, lane);
+}
+
+PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
+    const int P = build_pairs<true, true>(K, L, lane, alive, o, d, tMax);
+    ((float *)L.best)[lane] = tMax;
+    __syncthreads();
+    run_any_queue<false>(K, L, lane, P);
     __syncthreads();
     const bool occluded = alive && (L.occ[lane] != 0u);
     __syncthreads();
     return occluded;
+}
+
+// ---------------------------------------------------------------------------------
+// PMODE 3: a real TLAS (more meshes than one TLAS leaf holds) through the same pair machinery, in ROUNDS.
+// traceRay (intersection.cuh:526-605) walks the TLAS near child first and culls nodes with the closest hit so
+// far; at a leaf it traces every mesh from scratch (bvh_trace restarts at 1e30) and keeps strict `<` minima in
+// leaf order.  Here every lane walks the TLAS itself (a handful of nodes, stack in LDS) up to its next leaf; then
+// the wave turns the lanes' leaves into (ray, mesh) pairs -- index within the ray's own leaf as the tie order --
+// and drains them with run_closest_queue; every lane merges its leaf's minimum with strict `<` and walks on with
+// the updated limit.  So a mesh is traced iff the reference traces it.  Shadow rays do the same with the any-hit
+// walk (bvh_any_hit_tlas, intersection.cuh:481-524) and stop at the first blocked round.
+template <bool ANY>
+PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, bool has, int2 lf, const RayO &w, float tMax) {
+    L.leafx[lane] = lf.x;
+    if (!ANY)
+        L.best[lane] = ~0ull;
+    int base = 0;
+    for (int i = 0; i < K.tlas_max_leaf; ++i) {
+        bool hb = false;
+        if (has && i < lf.y) {
+            const int m = K.tlas_mesh_ids[lf.x + i];
+            const MeshHead mh = load_mesh_head(K, m);
+            if (!(ANY && (mh.flags & 2))) {
+                float tE;
+                if (mh.flags & 1) {
+                    float ds;
+                    const RayO lr = local_ray(K, m, w, ds);
+                    hb = slab(mh.bmin, mh.bmax, lr, ANY ? tMax * ds : T_FAR, tE);
+                } else {
+                    hb = slab(mh.bmin, mh.bmax, w, ANY ? tMax : T_FAR, tE);
+                }
+            }
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hb);
+        if (hb)
+            ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)i << 6));
+        base += __builtin_popcountll(bal);
+        if (!__builtin_amdgcn_ballot_w64(has && i + 1 < lf.y))
+            break;
+    }
+    return base;
+}
+
+PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
+    const RayO w = make_ray(o, d);
+    float tE;
+    bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, T_FAR, tE);
+    L.ray[0 * 64 + lane] = o.x;
+    L.ray[1 * 64 + lane] = o.y;
+    L.ray[2 * 64 + lane] = o.z;
+    L.ray[3 * 64 + lane] = d.x;
+    L.ray[4 * 64 + lane] = d.y;
+    L.ray[5 * 64 + lane] = d.z;
+    Hit best;
+    best.t = best.t_local = T_FAR;
+    best.u = best.v = 0.0f;
+    best.mesh = best.slot = -1;
+    int tcur = K.tlas_root_ref, tsp = 0;
+    bool need_pop = false;
+    auto pop_t = [&]() { // the next TLAS subtree that can still hold a closer hit (E1)
+        t_active = false;
+        while (tsp > 0) {
+            --tsp;
+            const uint2 e = L.tstack[tsp * 64 + lane];
+            if (__uint_as_float(e.y) < best.t) {
+                tcur = (int)e.x;
+                t_active = true;
+                break;
+            }
+        }
+    };
+    for (;;) {
+        int2 lf = make_int2(0, 0);
+        bool has = false;
+        if (need_pop)
+            pop_t();
+        while (t_active && !has) {
+            if (tcur >= 0) {
+                const float4 n0 = K.tlas_nodes[tcur * 4 + 0], n1 = K.tlas_nodes[tcur * 4 + 1], n2 = K.tlas_nodes[tcur * 4 + 2],
+                             n3 = K.tlas_nodes[tcur * 4 + 3];
+                float tL, tR;
+                const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, best.t, tL);
+                const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, best.t, tR);
+                const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+                if (hL || hR) {
+                    const bool nearL = hL && (!hR || tL <= tR);
+                    if (nearL ? hR : hL) {
+                        L.tstack[tsp * 64 + lane] = make_uint2((uint32_t)(nearL ? Rr : Lr), __float_as_uint(nearL ? tR : tL));
+                        ++tsp;
+                    }
+                    tcur = nearL ? Lr : Rr;
+                } else {
+                    pop_t();
+                }
+            } else {
+                lf = K.tlas_leaves[~tcur];
+                has = true;
+            }
+        }
+        need_pop = has;
+        if (!__builtin_amdgcn_ballot_w64(has))
+            break;
+        const int P = build_pairs_general<false>(K, L, lane, has, lf, w, T_FAR);
+        __syncthreads();
+        run_closest_queue<true>(K, L, lane, P);
+        __syncthreads();
+        const unsigned long long key = L.best[lane];
+        __syncthreads();
+        if (has && key != ~0ull) {
+            const float t = __uint_as_float((uint32_t)(key >> 32));
+            if (t < best.t) { // strict <: an earlier leaf keeps a tie (intersection.cuh:561)
+                best.t = t;
+                best.mesh = K.tlas_mesh_ids[lf.x + (int)((key >> 24) & 0xffu)];
+                best.slot = (int)(key & 0xffffffu);
+            }
+        }
+    }
+    best.t_local = best.t;
+    if (best.mesh >= 0 && (__float_as_int(K.mesh_recs[best.mesh * MESH_REC_F4 + 1].w) & 1))
+        best.t_local = winner_t_local(K, best.mesh, best.slot, o, d);
+    return best;
+}
+
+PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
+    const RayO w = make_ray(o, d);
+    float tE;
+    bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, tMax, tE);
+    L.ray[0 * 64 + lane] = o.x;
+    L.ray[1 * 64 + lane] = o.y;
+    L.ray[2 * 64 + lane] = o.z;
+    L.ray[3 * 64 + lane] = d.x;
+    L.ray[4 * 64 + lane] = d.y;
+    L.ray[5 * 64 + lane] = d.z;
+    ((float *)L.best)[lane] = tMax;
+    L.occ[lane] = 0u;
+    int tcur = K.tlas_root_ref, tsp = 0;
+    bool need_pop = false;
+    auto pop_t = [&]() {
+        t_active = false;
+        if (tsp > 0) {
+            --tsp;
+            tcur = (int)L.tstack[tsp * 64 + lane].x;
+            t_active = true;
+        }
+    };
+    __syncthreads();
+    for (;;) {
+        int2 lf = make_int2(0, 0);
+        bool has = false;
+        if (need_pop)
+            pop_t();
+        while (t_active && !has) {
+            if (tcur >= 0) {
+                const float4 n0 = K.tlas_nodes[tcur * 4 + 0], n1 = K.tlas_nodes[tcur * 4 + 1], n2 = K.tlas_nodes[tcur * 4 + 2],
+                             n3 = K.tlas_nodes[tcur * 4 + 3];
+                float tL, tR;
+                const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, tMax, tL);
+                const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, tMax, tR);
+                const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+                if (hL && hR) {
+                    L.tstack[tsp * 64 + lane] = make_uint2((uint32_t)Rr, 0u);
+                    ++tsp;
+                    tcur = Lr;
+                } else if (hL || hR) {
+                    tcur = hL ? Lr : Rr;
+                } else {
+                    pop_t();
+                }
+            } else {
+                lf = K.tlas_leaves[~tcur];
+                has = true;
+            }
+        }
+        need_pop = has;
+        if (!__builtin_amdgcn_ballot_w64(has))
+            break;
+        const int P = build_pairs_general<true>(K, L, lane, has, lf, w, tMax);
+        __syncthreads();
+        run_any_queue<true>(K, L, lane, P);
+        __syncthreads();
+        if (L.occ[lane] != 0u)
+            t_active = need_pop = false; // blocked: nothing more to look for
+        __syncthreads();
+    }
+    return alive && (L.occ[lane] != 0u);
 }
 
 // ---------------------------------------------------------------------------------
@@ -733,8 +950,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     PairLds PL{};
     if (PMODE) {
         const int staged = (PMODE == 1) ? K.pair_tri_slots : 0;
-        PL = carve_pair_lds((void *)lds_raw, staged, K.pair_meshes, PMODE == 2 ? K.stack_entries : 0);
-        const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+        PL = carve_pair_lds((void *)lds_raw, staged, PMODE == 3 ? 0 : K.pair_meshes, PMODE >= 2 ? K.stack_entries : 0,
+                            PMODE == 3 ? K.tlas_max_leaf : 0, PMODE == 3 ? K.tlas_depth : 0);
+        const int2 lf = PMODE == 3 ? make_int2(0, 0) : K.tlas_leaves[~K.tlas_root_ref];
         if (PMODE == 1) {
             // mesh i's packets start 2*i float4 (32 B) later than in the arena: with 48-B packets
             // the per-mesh blocks would otherwise sit a multiple of 16 banks apart and lanes working
@@ -746,7 +964,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
                     PL.tris[leaf.x * 3 + i * PAIR_PAD + k] = K.tris[leaf.x * 3 + k];
             }
         }
-        for (int i = lane; i < K.pair_meshes; i += 64) {
+        for (int i = lane; PMODE != 3 && i < K.pair_meshes; i += 64) {
             const int m = K.tlas_mesh_ids[lf.x + i];
             const MeshHead mh = load_mesh_head(K, m);
             if (PMODE == 1) {
@@ -835,6 +1053,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         // ---- [B] closest hit, all live lanes together
         const Hit h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd)
                       : (PMODE == 2) ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
+                      : (PMODE == 3) ? closest_hit_pairs_tlas(K, PL, lane, live, ro, rd)
                                      : closest_hit<GEOM>(K, live, ro, rd, stk);
 
         // ---- [C] first half of the shading
@@ -948,6 +1167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         if (__builtin_amdgcn_ballot_w64(want_shadow)) {
             in_shadow = (PMODE == 1)   ? any_hit_pairs(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
                         : (PMODE == 2) ? any_hit_pairs_dyn(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
+                        : (PMODE == 3) ? any_hit_pairs_tlas(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
                                        : any_hit<GEOM>(K, want_shadow, shadow_o, L, shadow_tmax, stk);
         }
 

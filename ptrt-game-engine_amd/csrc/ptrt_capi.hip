@@ -92,6 +92,7 @@ struct ptrt_ctx {
     bool tlas_single_leaf = false, all_single_leaf = false, mats_full = false;
     int stack_entries = 1;
     int pair_meshes = 0, pair_tri_slots = 0, pair_max_leaf = 0;
+    int tlas_max_leaf = 0, tlas_depth = 0;
     bool have_geometry = false, have_materials = false;
 
     pt::Camera cam{};
@@ -404,6 +405,8 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.pair_meshes = c->pair_meshes;
     K.pair_tri_slots = c->pair_tri_slots;
     K.pair_max_leaf = c->pair_max_leaf;
+    K.tlas_max_leaf = c->tlas_max_leaf;
+    K.tlas_depth = c->tlas_depth < 1 ? 1 : c->tlas_depth;
     K.pair_split = (c->pair_split && !c->any_transform) ? 1 : 0;
     K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
     K.leaf_pairs = c->leaf_pairs;
@@ -452,13 +455,21 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
 // in-wave (ray, mesh) pair compaction needs every BLAS to be one leaf and the staged
 // triangle packets to fit a modest LDS budget
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
+    if (pmode == 3) // no mesh table; pair list for one TLAS leaf per ray; TLAS stack + the rays' leaf starts
+        return (size_t)c->tlas_max_leaf * 128 + 6 * 256 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) +
+               (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 + 256 + pt::LEAF_PAIR_BYTES;
     const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * (pmode == 1 ? 256 : 128) + 6 * 256 + 512 + 256;
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
 }
 // 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
 int pair_mode(const ptrt_ctx *c, int geom) {
-    if (!c->pair_trace || c->pair_meshes <= 0)
+    if (!c->pair_trace)
+        return 0;
+    if (geom == 2) // a real TLAS: rounds of one leaf per ray (pt_render.hip.h)
+        return (c->tlas_max_leaf > 0 && c->tlas_max_leaf < 256 && c->pair_tri_slots < (1 << 24) && pair_lds_bytes(c, 3) <= 40 * 1024)
+                   ? 3 : 0;
+    if (c->pair_meshes <= 0)
         return 0;
     if (geom == 0 && c->pair_meshes < 65536 && c->pair_max_leaf < 65536 && pair_lds_bytes(c, 1) <= 40 * 1024)
         return 1;
@@ -1200,6 +1211,11 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     c->stack_entries = R.max_depth < 1 ? 1 : R.max_depth;
     c->pair_tri_slots = (int)(R.tris.size() / 3);
     c->pair_meshes = troot < 0 ? tleaves[~troot].y : 0;
+    c->tlas_depth = tdepth;
+    c->tlas_max_leaf = 0;
+    for (const int2 &lf : tleaves)
+        if (lf.y > c->tlas_max_leaf)
+            c->tlas_max_leaf = lf.y;
     c->pair_max_leaf = 0;
     for (const int2 &lf : R.leaves)
         if (lf.y > c->pair_max_leaf)
@@ -1616,6 +1632,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         launch_trace<0, 1>(c, K, full, grid, lds);
     else if (pmode == 2)
         launch_trace<1, 2>(c, K, full, grid, lds);
+    else if (pmode == 3)
+        launch_trace<2, 3>(c, K, full, grid, lds);
     else if (geom == 0)
         launch_trace<0, 0>(c, K, full, grid, lds);
     else if (geom == 1)

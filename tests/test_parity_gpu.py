@@ -62,12 +62,13 @@ def test_instanced_meshes(P, O, blue_noise):
         s.close()
 
 
-@pytest.mark.parametrize("leaf", [(1, 0), (2, 1), (4, 0)])
-def test_cornell_deep_bvh(P, O, blue_noise, leaf):
+@pytest.mark.parametrize("leaf,pair_trace", [((1, 0), 1), ((2, 1), 1), ((4, 0), 1), ((2, 1), 0)])
+def test_cornell_deep_bvh(P, O, blue_noise, leaf, pair_trace):
     """Small leaf targets turn every cube into a multi-level BLAS and the scene into a real TLAS."""
     s = P.Scene(72, 56)
     P.scenes.cornell(s)
     s.setBVHLeafTarget(*leaf)
+    s.set_option("pair_trace", pair_trace)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
     assert_frames_equal(gpu, cpu)
     s.close()
@@ -80,6 +81,40 @@ def test_cornell_one_lane_per_pair(P, O, blue_noise):
     s.set_option("pair_split", 0)
     gpu, cpu = render_both(P, O, s, blue_noise, 3, 4, 2)
     assert_frames_equal(gpu, cpu)
+    s.close()
+
+
+def _many_meshes(P, s, n=40, instanced=True):
+    """Cornell box + n small cubes and spheres (every third an instance with its own transform): more meshes than a
+    TLAS leaf holds, so the TLAS is a real tree."""
+    P.scenes.cornell(s)
+    rs = np.random.RandomState(3)
+    for k in range(n):
+        mat = P.Material(tuple(rs.uniform(0.2, 0.9, 3)), float(rs.uniform(0.05, 0.8)), float(k % 4 == 0),
+                         transmission=1.0 if k % 7 == 3 else 0.0, ior=1.4)
+        m = s.addSphere(5, mat) if k % 2 else s.addCube(mat)
+        pos = (float(rs.uniform(-4, 4)), float(rs.uniform(-4.5, 3.5)), float(rs.uniform(-9, -2)))
+        if instanced and k % 3 == 0:
+            s.setPosition(m, pos)
+            s.setRotation(m, tuple(rs.uniform(-1, 1, 3)))
+            s.setInstanceScale(m, tuple(rs.uniform(0.2, 0.5, 3)))
+        else:
+            s.scale(m, tuple(rs.uniform(0.2, 0.5, 3)))
+            s.moveTo(m, pos)
+
+
+@pytest.mark.parametrize("pair_trace,leaf", [(1, None), (0, None), (1, (2, 0)), (1, (4, 1))])
+def test_real_tlas_many_meshes(P, O, blue_noise, pair_trace, leaf):
+    """48 meshes -> a TLAS with inner nodes: PMODE 3 (per-lane TLAS walk, one leaf of (ray, mesh) pairs per round)
+    and, with pair_trace=0, the lock-step general traversal; also with small BLAS/TLAS leaf targets."""
+    s = P.Scene(96, 64)
+    _many_meshes(P, s)
+    if leaf:
+        s.setBVHLeafTarget(*leaf)
+    s.set_option("pair_trace", pair_trace)
+    gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
+    assert_frames_equal(gpu, cpu)
+    assert len(set(gpu[0]["object_id"].tolist())) > 20
     s.close()
 
 

@@ -1,4 +1,4 @@
-// pt_render.hip.h -- path_trace_kernel<GEOM,FULL,PAIRS>: the render loop (round-1 second cut).
+// pt_render.hip.h -- path_trace_kernel<GEOM,FULL,PMODE>: the render loop.
 //
 // Same outputs, bit for bit, as the first cut; what changed is how a wave spends its lanes:
 //
@@ -24,6 +24,15 @@
 //         smallest t wins, ties go to the earlier mesh, then the earlier triangle -- exactly
 //         the reference's strict-`<` first-minimum (equivalence E3 in pt_kernels.hip.h).
 //    Shadow rays use the same pairs with an LDS flag per ray instead of the min.
+//    A batch that does not fill the wave gives every pair 2^k lanes (pair_split).
+//
+//  * PMODE 2 (real BLASes behind a single-leaf TLAS) keeps the pair list as a QUEUE (run_closest_queue /
+//    run_any_queue): idle lanes refill by ballot rank; the node loop yields once leaf_min lanes wait at a
+//    leaf; the leaf phase runs as compacted (lane, triangle) pairs fed by ds_bpermute from the owner lane's
+//    registers; shadow rays share subtrees by stealing the bottom of busy lanes' stacks.  Measured lane
+//    occupancy before/after: profiles/r01e_lane_occupancy.txt, DESIGN.md 3.1.
+//  * PMODE 3 (a real TLAS) runs that queue in rounds, one TLAS leaf per ray per round.
+//  * PMODE 0: lock-step fall-backs (and the A/B baseline of the tests).
 #pragma once
 #include "pt_kernels.hip.h"
 

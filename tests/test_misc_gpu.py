@@ -151,7 +151,12 @@ def _frames(P, build, opts, W=1920, H=1080, spp=4, depth=4, n_frames=2):
     return out
 
 
-@pytest.mark.parametrize("scene", ["showcase", "fluid", "cornell"])
+def _many(P, s):
+    from test_parity_gpu import _many_meshes
+    _many_meshes(P, s, n=60)
+
+
+@pytest.mark.parametrize("scene", ["showcase", "fluid", "cornell", "many"])
 def test_full_size_traversal_variants_agree(P, scene):
     """BASELINE's full size (1920x1080, 4 spp / 2 spp for the fluid scene, 4 bounces, 2 frames): the default
     traversal -- pair queue, compacted leaf phase, shadow-ray subtree stealing, early-yielding descent, split
@@ -159,11 +164,13 @@ def test_full_size_traversal_variants_agree(P, scene):
     against the lock-step mesh loop, the asynchronous-lane kernel and the wavefront stages: every buffer, the generator states and the ray counts are equal.  16 M rays
     per frame reach the rare cases (exact-t ties on shared edges, hits on leaf-box faces) that small frames
     in the oracle tests may not."""
-    build = {"showcase": P.scenes.showcase, "cornell": P.scenes.cornell,
+    build = {"showcase": P.scenes.showcase, "cornell": P.scenes.cornell, "many": lambda s: _many(P, s),
              "fluid": lambda s: P.scenes.fluid(s, cells=256, t=0.3)}[scene]
     spp = 2 if scene == "fluid" else 4
     ref = _frames(P, build, {}, spp=spp)
     plain = dict(fetch_min=0, leaf_pairs=0, steal=0, leaf_min=64, pair_split=0)
+    # ("many": 68 meshes behind a real TLAS -- PMODE 3 rounds against plain rounds and the lock-step general walk;
+    #  the async / wavefront kernels take single-leaf TLASes only and fall back to the same default there)
     for opts in (plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):

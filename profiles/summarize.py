@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """Summarises gpurun_out/prof_<tag>/ (from profiles/pmc_pass.sh) into profiles/<round>_<tag>_{kernel_stats.csv,pmc.json}."""
-import collections, csv, glob, json, shutil, sys
+import collections, csv, glob, json, os, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/prof_{tag}"
-ks = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")
+ks = sorted(glob.glob(f"{src}/stats/*/*_kernel_stats.csv"), key=os.path.getmtime)  # gpurun merges runs: newest wins
 if ks:
-    shutil.copy(ks[0], f"profiles/{rnd}_{tag}_kernel_stats.csv")
+    shutil.copy(ks[-1], f"profiles/{rnd}_{tag}_kernel_stats.csv")
 out = {"tag": tag, "counters": {}}
+newest = {}
 for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
+    d = os.path.dirname(os.path.dirname(f))
+    if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+        newest[d] = f
+for f in newest.values():
     agg = collections.defaultdict(list)
     meta = None
     for r in csv.DictReader(open(f)):

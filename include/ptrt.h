@@ -209,6 +209,15 @@ int ptrt_upload_geometry(ptrt_ctx *ctx, const ptrt_mesh_desc *meshes, int mesh_c
                          const ptrt_bvh_node *tlas_nodes, int tlas_node_count,
                          const int32_t *tlas_mesh_indices, int tlas_index_count);
 
+/* Instances moved, nothing else changed -- the transform-dirty case of Scene::updateAccelerationStructures
+ * (scene.cuh:656-743) and of commitObjectChanges (scene.cuh:1784-1787): takes the new world / inverse /
+ * normal matrices and has_transform flags of every mesh and the rebuilt TLAS; vertices, BLASes and triangle
+ * packets on the device stay where they are (a full ptrt_upload_geometry re-lays-out every triangle).
+ * mesh_count must equal the uploaded one; the other mesh fields are not read. */
+int ptrt_update_instances(ptrt_ctx *ctx, const ptrt_mesh_desc *meshes, int mesh_count,
+                          const ptrt_bvh_node *tlas_nodes, int tlas_node_count,
+                          const int32_t *tlas_mesh_indices, int tlas_index_count);
+
 /* Scene::uploadMaterialSoA (scene.cuh:286-431). */
 int ptrt_upload_materials(ptrt_ctx *ctx, const ptrt_materials *mats);
 

@@ -140,6 +140,7 @@ struct ptrt_ctx {
     size_t wf_items = 0;
     int wf_trace_blocks = 0;
     size_t wf_trace_lds = 0;
+    int n_geometry_uploads = 0, n_instance_updates = 0;
     bool any_transform = false; // some mesh is an instance with its own transform
     int pair_split = 1;         // option (A/B, tests)
     int last_mode = 0; // how the last frame was rendered: 0 megakernel, 1 wavefront stages, 2 asynchronous lanes
@@ -328,6 +329,54 @@ int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nod
         o[3] = f4(as_f(L), as_f(R), 0.0f, 0.0f);
     }
     return root;
+}
+
+// TLAS part of an upload: converts the reference-shaped TLAS, uploads it and derives what the launch needs of it
+int upload_tlas(ptrt_ctx *c, int mesh_count, const ptrt_bvh_node *tlas_nodes, int tlas_node_count,
+                const int32_t *tlas_mesh_indices, int tlas_index_count, bool dry_run) {
+    std::vector<float4> tnodes;
+    std::vector<int2> tleaves;
+    bool bad = false;
+    std::string why;
+    auto emit_tleaf = [&](int start, int count, int) -> int {
+        if (count > 0 && (start < 0 || start + count > tlas_index_count)) {
+            bad = true;
+            count = 0;
+        }
+        tleaves.push_back(make_int2(start < 0 ? 0 : start, count));
+        return (int)tleaves.size() - 1;
+    };
+    int tdepth = 0;
+    const int troot = convert_tree(tlas_nodes, tlas_node_count, tnodes, emit_tleaf, tdepth, why);
+    if (troot == INT32_MIN || bad)
+        return fail(c, PTRT_E_INVALID, "malformed TLAS (%s)", bad ? "leaf range out of bounds" : why.c_str());
+    if (tdepth > 23)
+        return fail(c, PTRT_E_INVALID, "TLAS is %d levels deep; needs <= 23", tdepth);
+    std::vector<int> tids(tlas_mesh_indices, tlas_mesh_indices + tlas_index_count);
+    for (int id : tids)
+        if (id < 0 || id >= mesh_count)
+            return fail(c, PTRT_E_INVALID, "TLAS references mesh %d of %d", id, mesh_count);
+    if (dry_run)
+        return PTRT_OK;
+    std::vector<float4> rootbox = {f4(tlas_nodes[0].bmin.x, tlas_nodes[0].bmin.y, tlas_nodes[0].bmin.z, 0.0f),
+                                   f4(tlas_nodes[0].bmax.x, tlas_nodes[0].bmax.y, tlas_nodes[0].bmax.z, 0.0f)};
+    if (int rc = upload(c, c->d_tlas_root_box, rootbox))
+        return rc;
+    if (int rc = upload(c, c->d_tlas_nodes, tnodes))
+        return rc;
+    if (int rc = upload(c, c->d_tlas_leaves, tleaves))
+        return rc;
+    if (int rc = upload(c, c->d_tlas_mesh_ids, tids))
+        return rc;
+    c->tlas_root_ref = troot;
+    c->tlas_single_leaf = troot < 0;
+    c->pair_meshes = troot < 0 ? tleaves[~troot].y : 0;
+    c->tlas_depth = tdepth;
+    c->tlas_max_leaf = 0;
+    for (const int2 &lf : tleaves)
+        if (lf.y > c->tlas_max_leaf)
+            c->tlas_max_leaf = lf.y;
+    return PTRT_OK;
 }
 
 void drop_graphs(ptrt_ctx *c);
@@ -1109,28 +1158,9 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
             rec[8 + r] = f4(M.normal[r * 4], M.normal[r * 4 + 1], M.normal[r * 4 + 2], 0.0f);
         }
     }
-    // TLAS
-    std::vector<float4> tnodes;
-    std::vector<int2> tleaves;
-    bool bad = false;
-    auto emit_tleaf = [&](int start, int count, int) -> int {
-        if (count > 0 && (start < 0 || start + count > tlas_index_count)) {
-            bad = true;
-            count = 0;
-        }
-        tleaves.push_back(make_int2(start < 0 ? 0 : start, count));
-        return (int)tleaves.size() - 1;
-    };
-    int tdepth = 0;
-    const int troot = convert_tree(tlas_nodes, tlas_node_count, tnodes, emit_tleaf, tdepth, why);
-    if (troot == INT32_MIN || bad)
-        return fail(c, PTRT_E_INVALID, "malformed TLAS (%s)", bad ? "leaf range out of bounds" : why.c_str());
-    if (tdepth > 23)
-        return fail(c, PTRT_E_INVALID, "TLAS is %d levels deep; needs <= 23", tdepth);
-    std::vector<int> tids(tlas_mesh_indices, tlas_mesh_indices + tlas_index_count);
-    for (int id : tids)
-        if (id < 0 || id >= mesh_count)
-            return fail(c, PTRT_E_INVALID, "TLAS references mesh %d of %d", id, mesh_count);
+    // TLAS: validated before anything of the old scene is freed, uploaded below
+    if (int rc = upload_tlas(c, mesh_count, tlas_nodes, tlas_node_count, tlas_mesh_indices, tlas_index_count, true))
+        return rc;
 
     free_scene(c);
     c->n_meshes = mesh_count;
@@ -1161,10 +1191,6 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
         for (int i = 0; i < (int)node_depth.size(); ++i)
             if (node_depth[i] >= 1)
                 level_nodes[(size_t)fill[node_depth[i] - 1]++] = i;
-        std::vector<float4> rootbox = {f4(tlas_nodes[0].bmin.x, tlas_nodes[0].bmin.y, tlas_nodes[0].bmin.z, 0.0f),
-                                       f4(tlas_nodes[0].bmax.x, tlas_nodes[0].bmax.y, tlas_nodes[0].bmax.z, 0.0f)};
-        if (int rc = upload(c, c->d_tlas_root_box, rootbox))
-            return rc;
         if (int rc = upload(c, c->d_verts, all_verts))
             return rc;
         if (int rc = upload(c, c->d_slot_face, slot_face))
@@ -1196,31 +1222,70 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
         return rc;
     if (int rc = upload(c, c->d_tris, R.tris))
         return rc;
-    if (int rc = upload(c, c->d_tlas_nodes, tnodes))
+    if (int rc = upload_tlas(c, mesh_count, tlas_nodes, tlas_node_count, tlas_mesh_indices, tlas_index_count, false))
         return rc;
-    if (int rc = upload(c, c->d_tlas_leaves, tleaves))
-        return rc;
-    if (int rc = upload(c, c->d_tlas_mesh_ids, tids))
-        return rc;
-    c->tlas_root_ref = troot;
-    c->tlas_single_leaf = troot < 0;
+    c->n_geometry_uploads++;
     c->all_single_leaf = all_leaf;
     c->any_transform = false;
     for (int m = 0; m < mesh_count; ++m)
         c->any_transform = c->any_transform || meshes[m].has_transform != 0;
     c->stack_entries = R.max_depth < 1 ? 1 : R.max_depth;
     c->pair_tri_slots = (int)(R.tris.size() / 3);
-    c->pair_meshes = troot < 0 ? tleaves[~troot].y : 0;
-    c->tlas_depth = tdepth;
-    c->tlas_max_leaf = 0;
-    for (const int2 &lf : tleaves)
-        if (lf.y > c->tlas_max_leaf)
-            c->tlas_max_leaf = lf.y;
     c->pair_max_leaf = 0;
     for (const int2 &lf : R.leaves)
         if (lf.y > c->pair_max_leaf)
             c->pair_max_leaf = lf.y;
     c->have_geometry = true;
+    return PTRT_OK;
+}
+
+// Instances moved, nothing else changed (Scene::updateAccelerationStructures for a mesh whose transform is dirty,
+// scene.cuh:656-743): new matrices and has_transform flags into the mesh records, new TLAS; vertices, BLASes and
+// triangle packets stay where they are.
+int ptrt_update_instances(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count, const ptrt_bvh_node *tlas_nodes,
+                          int tlas_node_count, const int32_t *tlas_mesh_indices, int tlas_index_count) {
+    if (!ctx_live(c) || !meshes || !tlas_nodes || !tlas_mesh_indices || tlas_node_count <= 0 || tlas_index_count <= 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_update_instances: bad argument");
+    if (!c->have_geometry)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_update_instances: geometry not uploaded");
+    if (mesh_count != c->n_meshes)
+        return fail(c, PTRT_E_INVALID, "ptrt_update_instances: %d meshes, %d uploaded (use ptrt_upload_geometry)", mesh_count,
+                    c->n_meshes);
+    if (int rc = set_device(c))
+        return rc;
+    if (int rc = upload_tlas(c, mesh_count, tlas_nodes, tlas_node_count, tlas_mesh_indices, tlas_index_count, true))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // frames in flight still read the old records
+    c->any_transform = false;
+    for (int m = 0; m < mesh_count; ++m) {
+        const ptrt_mesh_desc &M = meshes[m];
+        float4 *rec = &c->h_mesh_recs[(size_t)m * pt::MESH_REC_F4];
+        int flags;
+        std::memcpy(&flags, &rec[1].w, 4);
+        flags = (flags & ~1) | (M.has_transform ? 1 : 0);
+        rec[1].w = as_f(flags);
+        for (int r = 0; r < 3; ++r) {
+            rec[2 + r] = f4(M.inverse[r * 4], M.inverse[r * 4 + 1], M.inverse[r * 4 + 2], M.inverse[r * 4 + 3]);
+            rec[5 + r] = f4(M.world[r * 4], M.world[r * 4 + 1], M.world[r * 4 + 2], M.world[r * 4 + 3]);
+            rec[8 + r] = f4(M.normal[r * 4], M.normal[r * 4 + 1], M.normal[r * 4 + 2], 0.0f);
+        }
+        c->any_transform = c->any_transform || M.has_transform != 0;
+    }
+    if (int rc = push_mesh_recs(c, true))
+        return rc;
+    if (int rc = upload_tlas(c, mesh_count, tlas_nodes, tlas_node_count, tlas_mesh_indices, tlas_index_count, false))
+        return rc;
+    drop_graphs(c);
+    c->n_instance_updates++;
+    return PTRT_OK;
+}
+
+// test hook: how often each kind of acceleration-structure upload ran
+int ptrt_debug_upload_counts(ptrt_ctx *c, int *out2) {
+    if (!ctx_live(c) || !out2)
+        return PTRT_E_INVALID;
+    out2[0] = c->n_geometry_uploads;
+    out2[1] = c->n_instance_updates;
     return PTRT_OK;
 }
 

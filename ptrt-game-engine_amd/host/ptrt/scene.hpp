@@ -724,6 +724,7 @@ class Scene {
 
     ptrt_ctx *ctx = nullptr;
     bool geometryDirty = true, materialsDirty = true, lightsDirty = true, cameraDirty = true, skyDirty = true;
+    bool instancesDirty = false; // only instance transforms (and with them the TLAS) changed since the last upload
     bool warnedPost = false, denoiserAllocated = false;
     std::vector<float> envMap;                // RGBA floats of the HDRI sky (empty: gradient)
     int env_width = 0, env_height = 0;
@@ -845,9 +846,9 @@ class Scene {
                 m->transform.updateMatrices();
             else
                 moved = std::memcmp(&lastWorld[i], &m->transform.worldMatrix, sizeof(mat4)) != 0;
-            if (moved) {
+            if (moved) { // an instance moved: new matrices + TLAS, the triangles stay (ptrt_update_instances)
                 tlas_dirty = true;
-                geometryDirty = true;
+                instancesDirty = true;
             }
             lastWorld[i] = m->transform.worldMatrix;
             ptrt_mesh_desc &d = flatMeshes[i];
@@ -927,7 +928,12 @@ class Scene {
             check(ptrt_upload_geometry(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,
                                        flat.tlas_mesh_indices, flat.tlas_index_count),
                   "Failed to upload geometry");
-            geometryDirty = false;
+            geometryDirty = instancesDirty = false;
+        } else if (instancesDirty) {
+            check(ptrt_update_instances(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,
+                                        flat.tlas_mesh_indices, flat.tlas_index_count),
+                  "Failed to update instances");
+            instancesDirty = false;
         }
         if (materialsDirty) {
             check(ptrt_upload_materials(ctx, &flat.materials), "Failed to upload materials");

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTRT_ABI_VERSION 2 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height */
+#define PTRT_ABI_VERSION 3 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height; 3: + ptrt_post_frame, ptrt_update_instances (additions only) */
 
 enum {
     PTRT_OK = 0,

@@ -622,253 +622,8 @@ PT_DEV LightRec load_light(const float4 *__restrict__ L, int i) {
 }
 
 // ---------------------------------------------------------------------------------
-// the render loop: see pt_render.hip.h (the first-round kernel below is kept for reference
-// only and is not compiled)
+// the render loop itself: pt_render.hip.h
 // ---------------------------------------------------------------------------------
-#if 0
-template <int GEOM, bool FULL> __global__ __launch_bounds__(64) void path_trace_kernel(const KParams K) {
-    extern __shared__ uint2 lds_stack[];
-    const int lane = threadIdx.x;
-    LdsStack stk{lds_stack + lane};
-    const int tile = blockIdx.x;
-    const int tx = tile % K.tiles_x, ty = tile / K.tiles_x;
-    const int x = tx * 8 + (lane & 7);
-    const int yl = ty * 8 + (lane >> 3);
-    const bool inside = (x < K.width) && (yl < K.rows);
-    const int y = K.y0 + yl;
-    const size_t npix = (size_t)K.rows * K.width;
-    const size_t idx = (size_t)yl * K.width + x;
-
-    Rng rng = {0, 0, 0, 0, 0, 0};
-    if (inside) {
-        rng.d = K.rng[idx];
-        rng.v0 = K.rng[npix + idx];
-        rng.v1 = K.rng[2 * npix + idx];
-        rng.v2 = K.rng[3 * npix + idx];
-        rng.v3 = K.rng[4 * npix + idx];
-        rng.v4 = K.rng[5 * npix + idx];
-    }
-
-    f3 avg_color = mk3(0.0f);
-    f3 first_normal = mk3(0.0f);
-    float first_depth = 1e30f;
-    int first_id = -1;
-    uint32_t n_ext = 0, n_shadow = 0;
-
-    int s = inside ? 0 : K.spp;
-    int bounce = 0;
-    bool fresh = true;
-    f3 ro = mk3(0.0f), rd = mk3(0.0f);
-    bool ray_spec = true, prev_was_specular = true;
-    f3 throughput = mk3(1.0f), acc = mk3(0.0f);
-
-    while (__builtin_amdgcn_ballot_w64(s < K.spp)) {
-        const bool live = s < K.spp;
-        if (live && fresh) {
-            // primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
-            float tjx, tjy, bnx, bny;
-            taa_jitter(K.frame_count + s, tjx, tjy);
-            blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);
-            const float jitter_x = tjx + (bnx - 0.5f) * 0.25f;
-            const float jitter_y = tjy + (bny - 0.5f) * 0.25f;
-            const float u = ((float)x + 0.5f + jitter_x) / (float)K.width;
-            const float v = 1.0f - ((float)y + 0.5f + jitter_y) / (float)K.height;
-            if (K.cam.lens_radius <= 0) {
-                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin;
-                ro = K.cam.origin;
-                rd = normalize(dir);
-            } else {
-                f3 p;
-                do {
-                    const float a = rng_uniform(rng);
-                    const float b = rng_uniform(rng);
-                    p = 2.0f * mk3(a, b, 0.0f) - mk3(1.0f, 1.0f, 0.0f);
-                } while (dot(p, p) >= 1.0f);
-                const f3 rdisk = K.cam.lens_radius * p;
-                const f3 offset = K.cam.u * rdisk.x + K.cam.v * rdisk.y;
-                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin - offset;
-                ro = K.cam.origin + offset;
-                rd = normalize(dir);
-            }
-            ray_spec = true;
-            prev_was_specular = true;
-            throughput = mk3(1.0f);
-            acc = mk3(0.0f);
-            bounce = 0;
-            fresh = false;
-        }
-
-        const Hit h = closest_hit<GEOM>(K, live, ro, rd, stk);
-        if (live) {
-            ++n_ext;
-            bool end_path = false;
-            if (h.mesh < 0) {
-                if (bounce == 0 && s == 0) {
-                    first_normal = mk3(0.0f);
-                    first_depth = 1e30f;
-                    first_id = -1;
-                }
-                if (K.use_sky) { // sampleSky, gradient (render_utils.cuh:115-125)
-                    const float t = 0.5f * (rd.y + 1.0f);
-                    acc = acc + throughput * lerp(K.sky_bottom, K.sky_top, t);
-                } else {
-                    acc = acc + throughput * mk3(0.0f);
-                }
-                end_path = true;
-            } else {
-                const Surface hit = make_surface(K, h, ro, rd, nullptr, nullptr);
-                if (bounce == 0 && s == 0) {
-                    first_normal = hit.normal;
-                    first_depth = hit.t;
-                    first_id = h.mesh;
-                }
-                const Material mat = load_material(K.materials, h.mesh);
-                const f3 V = -rd;
-                if (!hit.front_face) { // Beer-Lambert on back faces (path_logic.cuh:823-829)
-                    const f3 T_unit = mk3(max_(1e-6f, mat.albedo.x), max_(1e-6f, mat.albedo.y), max_(1e-6f, mat.albedo.z));
-                    const f3 absorption = mk3(-det_log(T_unit.x), -det_log(T_unit.y), -det_log(T_unit.z));
-                    throughput = throughput * beerLambert(absorption, hit.t);
-                }
-                if (mat.emission.x > 0.0f || mat.emission.y > 0.0f || mat.emission.z > 0.0f) {
-                    if (bounce == 0 || prev_was_specular)
-                        acc = acc + throughput * mat.emission;
-                }
-                // next-event estimation (path_logic.cuh:305-393, 840-857)
-                if (!ray_spec && K.n_lights > 0) {
-                    float r = rng_uniform(rng);
-                    r = min_(r, 0.99999994f);
-                    const int light_index = (int)(r * (float)K.n_lights);
-                    const LightRec light = load_light(K.lights, light_index);
-                    const float pdf_pick = 1.0f / (float)K.n_lights;
-                    f3 L;
-                    float attenuation = 1.0f;
-                    float light_dist = 1e30f;
-                    const f3 light_radiance = light.color * light.intensity;
-                    float pdf_sample = 1.0f;
-                    if (light.type == 1) {
-                        L = -light.direction;
-                        pdf_sample = pdf_pick;
-                    } else {
-                        const f3 toLight = light.position - hit.point;
-                        const float light_dist_sq = dot(toLight, toLight);
-                        light_dist = __builtin_sqrtf(light_dist_sq);
-                        if (light.radius <= 0.0f) {
-                            L = toLight / light_dist;
-                            pdf_sample = pdf_pick;
-                        } else {
-                            float sin_theta_max_sq = (light.radius * light.radius) / light_dist_sq;
-                            sin_theta_max_sq = min_(sin_theta_max_sq, 0.9999f);
-                            const float cos_theta_max = __builtin_sqrtf(1.0f - sin_theta_max_sq);
-                            L = sample_cone_direction(rng, toLight / light_dist, cos_theta_max);
-                            const float solid_angle = TWO_PI_F * (1.0f - cos_theta_max);
-                            pdf_sample = (solid_angle > 1e-6f) ? (pdf_pick / solid_angle) : pdf_pick;
-                        }
-                        attenuation = attenuate(light_dist, light.range);
-                        if (light.type == 2) {
-                            const float theta = dot(L, -light.direction);
-                            const float epsilon = light.inner - light.outer;
-                            float spotIntensity;
-                            if (epsilon <= 1e-6f)
-                                spotIntensity = (theta >= light.outer) ? 1.0f : 0.0f;
-                            else
-                                spotIntensity = clampf((theta - light.outer) / epsilon, 0.0f, 1.0f);
-                            attenuation *= spotIntensity;
-                        }
-                    }
-                    const f3 shadow_offset = dot(hit.normal, L) > 0.0f ? hit.normal * 1e-4f : -hit.normal * 1e-4f;
-                    ++n_shadow;
-                    const bool inShadow = any_hit<GEOM>(K, true, hit.point + shadow_offset, L, light_dist - 1e-3f, stk);
-                    if (!inShadow) {
-                        const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
-                        if (pdf_sample > 0.0f) {
-                            f3 direct = bsdf * light_radiance * attenuation / pdf_sample;
-                            direct = clamp_vector_soft(direct, 500.0f);
-                            if (direct.x > 0.0f || direct.y > 0.0f || direct.z > 0.0f) {
-                                const float pdf_brdf = material_pdf<FULL>(hit, mat, V, L);
-                                const float wgt = mis_weight(pdf_sample, pdf_brdf);
-                                acc = acc + throughput * direct * wgt;
-                            }
-                        }
-                    }
-                }
-                f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
-                bool is_specular = false;
-                if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular)) {
-                    end_path = true;
-                } else {
-                    prev_was_specular = is_specular;
-                    bool killed = false;
-                    if (bounce >= 2) { // Russian roulette (path_logic.cuh:871-880)
-                        const float p = max_(0.05f, min_(0.95f, max_(throughput.x, max_(throughput.y, throughput.z))));
-                        if (rng_uniform(rng) > p)
-                            killed = true;
-                        else
-                            throughput = throughput / p;
-                    }
-                    if (killed) {
-                        end_path = true;
-                    } else {
-                        throughput = throughput * att;
-                        throughput = clamp_vector_soft(throughput, 50.0f);
-                        const f3 off = hit.normal * 1e-4f;
-                        ro = (dot(scatter_dir, hit.normal) > 0.0f) ? (hit.point + off) : (hit.point - off);
-                        rd = scatter_dir;
-                        ray_spec = is_specular;
-                        ++bounce;
-                        if (bounce >= K.max_depth)
-                            end_path = true;
-                    }
-                }
-            }
-            if (end_path) {
-                acc = clamp_vector_soft(acc, 100.0f);
-                avg_color = avg_color + acc;
-                ++s;
-                fresh = true;
-            }
-        }
-    }
-
-    if (inside) {
-        K.rng[idx] = rng.d;
-        K.rng[npix + idx] = rng.v0;
-        K.rng[2 * npix + idx] = rng.v1;
-        K.rng[3 * npix + idx] = rng.v2;
-        K.rng[4 * npix + idx] = rng.v3;
-        K.rng[5 * npix + idx] = rng.v4;
-        const f3 out = avg_color / (float)K.spp;
-        K.accum[idx * 3 + 0] = out.x;
-        K.accum[idx * 3 + 1] = out.y;
-        K.accum[idx * 3 + 2] = out.z;
-        K.normal[idx * 3 + 0] = first_normal.x;
-        K.normal[idx * 3 + 1] = first_normal.y;
-        K.normal[idx * 3 + 2] = first_normal.z;
-        K.depth[idx] = first_depth;
-        K.object_id[idx] = first_id;
-        // tonemap_kernel fused: RGB8, rows flipped within the tile (scene.cuh:2013-2015)
-        unsigned char r8, g8, b8;
-        tonemap_pixel(out, r8, g8, b8);
-        const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
-        K.rgb8[o + 0] = r8;
-        K.rgb8[o + 1] = g8;
-        K.rgb8[o + 2] = b8;
-    }
-    if (K.counters) {
-        uint32_t a = n_ext, b = n_shadow, c = inside ? (uint32_t)K.spp : 0u;
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off);
-            b += __shfl_xor(b, off);
-            c += __shfl_xor(c, off);
-        }
-        if (lane == 0) {
-            atomicAdd(&K.counters[0], (unsigned long long)a);
-            atomicAdd(&K.counters[1], (unsigned long long)b);
-            atomicAdd(&K.counters[2], (unsigned long long)c);
-        }
-    }
-}
-
-#endif // first-round kernel
 
 // ---------------------------------------------------------------------------------
 // XORWOW initialisation: state(seed) advanced by `global pixel index` subsequences of

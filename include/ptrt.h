@@ -213,7 +213,8 @@ int ptrt_upload_geometry(ptrt_ctx *ctx, const ptrt_mesh_desc *meshes, int mesh_c
  * (scene.cuh:656-743) and of commitObjectChanges (scene.cuh:1784-1787): takes the new world / inverse /
  * normal matrices and has_transform flags of every mesh and the rebuilt TLAS; vertices, BLASes and triangle
  * packets on the device stay where they are (a full ptrt_upload_geometry re-lays-out every triangle).
- * mesh_count must equal the uploaded one; the other mesh fields are not read. */
+ * mesh_count must equal the uploaded one; the other mesh fields are not read, and the meshes' root boxes on
+ * the device (which a ptrt_refit / ptrt_build_bvh may have moved since the upload) are left alone. */
 int ptrt_update_instances(ptrt_ctx *ctx, const ptrt_mesh_desc *meshes, int mesh_count,
                           const ptrt_bvh_node *tlas_nodes, int tlas_node_count,
                           const int32_t *tlas_mesh_indices, int tlas_index_count);
@@ -247,7 +248,9 @@ int ptrt_set_env_map(ptrt_ctx *ctx, const float *rgba, int width, int height);
  * verts_on_device != 0) and ptrt_refit() re-derives, on the GPU and on the context's stream,
  * the triangle packets, every leaf and inner box of the dirty meshes (bottom-up over the
  * UNCHANGED tree), the mesh root boxes and the TLAS root box.  No host synchronisation.
- * Requires a single-leaf TLAS (<= leaf-target+tol meshes).  A refitted tree has the boxes a
+ * With a TLAS that has inner nodes (more meshes than one TLAS leaf holds) the TLAS itself is left to the
+ * caller: rebuild it over the moved meshes' boxes, as the reference's commit does, and hand it to
+ * ptrt_update_instances (the Scene mirror's refitObjectChanges / rebuildObjectChanges do).  A refitted tree has the boxes a
  * host refit of the same topology gives (min/max are exact), so results stay bit-comparable
  * with the oracle run on those arrays; it is NOT the tree a fresh median-split build would give. */
 int ptrt_update_vertices(ptrt_ctx *ctx, int mesh_index, const float *verts, int vert_count, int verts_on_device);

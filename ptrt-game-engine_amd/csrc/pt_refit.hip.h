@@ -128,7 +128,8 @@ __global__ __launch_bounds__(1024) void refit_top_levels_kernel(const int *__res
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0)
+    // (a TLAS with inner nodes is rebuilt by the host over the refitted mesh boxes: ptrt_update_instances)
+    if (threadIdx.x == 0 && root_ref < 0)
         tlas_root_box(mesh_recs, tlas_leaves, tlas_mesh_ids, root_ref, root_box);
 }
 

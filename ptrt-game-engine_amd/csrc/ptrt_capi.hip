@@ -1270,9 +1270,14 @@ int ptrt_update_instances(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_co
             rec[8 + r] = f4(M.normal[r * 4], M.normal[r * 4 + 1], M.normal[r * 4 + 2], 0.0f);
         }
         c->any_transform = c->any_transform || M.has_transform != 0;
+        // flags word and the nine matrix rows only: the root box (rec[0].xyz, rec[1].xyz) on the device may have
+        // been moved by ptrt_refit / ptrt_build_bvh since the upload and stays as it is
+        HIP_TRY(c, hipMemcpyAsync(&c->d_mesh_recs[(size_t)m * pt::MESH_REC_F4 + 1].w, &rec[1].w, 4, hipMemcpyHostToDevice,
+                                  c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&c->d_mesh_recs[(size_t)m * pt::MESH_REC_F4 + 2], &rec[2], 9 * sizeof(float4),
+                                  hipMemcpyHostToDevice, c->stream));
     }
-    if (int rc = push_mesh_recs(c, true))
-        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (int rc = upload_tlas(c, mesh_count, tlas_nodes, tlas_node_count, tlas_mesh_indices, tlas_index_count, false))
         return rc;
     drop_graphs(c);
@@ -1394,8 +1399,6 @@ int ptrt_refit(ptrt_ctx *c) {
         return fail(c, PTRT_E_INVALID, "ptrt_refit: bad context");
     if (!c->have_geometry)
         return fail(c, PTRT_E_NOT_READY, "ptrt_refit: geometry not uploaded");
-    if (!c->tlas_single_leaf)
-        return fail(c, PTRT_E_INVALID, "ptrt_refit: needs a single-leaf TLAS; rebuild and re-upload instead");
     if (int rc = set_device(c))
         return rc;
     return run_graphed(c, -1, [c](hipStream_t st) { return enqueue_refit(c, st); });
@@ -1411,8 +1414,6 @@ int ptrt_build_bvh(ptrt_ctx *c, int mesh) {
     if (!c->mesh_rebuildable[mesh])
         return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: mesh %d's uploaded BVH does not place every face in exactly one "
                                        "leaf position; rebuild on the host and re-upload", mesh);
-    if (!c->tlas_single_leaf)
-        return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: needs a single-leaf TLAS; rebuild and re-upload instead");
     if (int rc = set_device(c))
         return rc;
     const int n = c->mesh_face_count[mesh];

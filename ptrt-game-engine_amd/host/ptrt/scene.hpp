@@ -478,9 +478,22 @@ class Scene {
                   "Failed to update vertices");
         }
         check(ptrt_refit(ctx), "Failed to refit");
-        buildTLAS(); // host copy of the (single-node) TLAS box
-        flat.tlas_nodes = h_tlasNodes.data();
+        syncTLAS();
         resetAccumulation();
+    }
+    // TLAS over the meshes' new boxes: the host copy always; the device copy too when the TLAS has inner nodes
+    // (the GPU refit moves the root box of a single-leaf TLAS itself and leaves a real TLAS to the host, which
+    // rebuilds it as the reference's commit does)
+    void syncTLAS() {
+        buildTLAS();
+        flat.tlas_nodes = h_tlasNodes.data();
+        flat.tlas_node_count = (int)h_tlasNodes.size();
+        flat.tlas_mesh_indices = h_tlasMeshIndices.data();
+        flat.tlas_index_count = (int)h_tlasMeshIndices.size();
+        if (h_tlasNodes.size() > 1)
+            check(ptrt_update_instances(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,
+                                        flat.tlas_mesh_indices, flat.tlas_index_count),
+                  "Failed to update the TLAS");
     }
     // same, the new positions already being in device memory (no host copy is kept: flatten()
     // then describes the LAST host-side vertices)
@@ -489,6 +502,9 @@ class Scene {
         Mesh *m = getMesh(mesh);
         if (!m)
             throw std::runtime_error("refitFromDevice: no such mesh");
+        if (h_tlasNodes.size() > 1)
+            throw std::runtime_error("refitFromDevice: a TLAS with inner nodes is rebuilt on the host, which needs the "
+                                     "vertices (use setVertices + refitObjectChanges)");
         check(ptrt_update_vertices(ctx, (int)mesh, device_xyz, (int)m->vertices.size(), 1), "Failed to update vertices");
         check(ptrt_refit(ctx), "Failed to refit");
         resetAccumulation();
@@ -513,10 +529,10 @@ class Scene {
             if (syncHostCopy)
                 syncPrimOrder(i);
         }
-        if (syncHostCopy) {
-            buildTLAS();
-            flat.tlas_nodes = h_tlasNodes.data();
-        }
+        if (syncHostCopy)
+            syncTLAS();
+        else if (h_tlasNodes.size() > 1)
+            throw std::runtime_error("rebuildObjectChanges: a TLAS with inner nodes needs the host copy (syncHostCopy)");
         resetAccumulation();
     }
     // same, new positions already in device memory (host copy not updated)
@@ -525,6 +541,9 @@ class Scene {
         Mesh *m = getMesh(mesh);
         if (!m)
             throw std::runtime_error("rebuildFromDevice: no such mesh");
+        if (h_tlasNodes.size() > 1)
+            throw std::runtime_error("rebuildFromDevice: a TLAS with inner nodes is rebuilt on the host, which needs the "
+                                     "vertices (use setVertices + rebuildObjectChanges)");
         check(ptrt_update_vertices(ctx, (int)mesh, device_xyz, (int)m->vertices.size(), 1), "Failed to update vertices");
         check(ptrt_build_bvh(ctx, (int)mesh), "Failed to build BVH");
         resetAccumulation();
@@ -547,8 +566,7 @@ class Scene {
                 m->vertices[v] = real ? vec3(verts9[s * 3], verts9[s * 3 + 1], verts9[s * 3 + 2]) : vec3(0.0f);
             }
             syncPrimOrder(mesh);
-            buildTLAS();
-            flat.tlas_nodes = h_tlasNodes.data();
+            syncTLAS();
         }
         resetAccumulation();
     }

@@ -89,3 +89,43 @@ def test_refit_from_device_memory(P, O, blue_noise):
     # wrong vertex count is rejected
     assert P.lib.ptrt_update_vertices(s.ctx, w, good.data_ptr() and None, 7, 1) == -1
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rebuild", [False, True])
+def test_refit_and_rebuild_behind_a_real_tlas(P, O, blue_noise, rebuild):
+    """A vertex-animated mesh among > 17 meshes: BLAS refit (or GPU rebuild) on the GPU, TLAS rebuilt by the host
+    over the new boxes and handed over with ptrt_update_instances; frames equal the oracle's over the host copy."""
+    from test_parity_gpu import _many_meshes
+    from common import assert_frames_equal
+    W, H, spp, depth = 80, 60, 2, 4
+    s = P.Scene(W, H)
+    _many_meshes(P, s, n=24)
+    blob = s.addSphere(16, P.Material((0.8, 0.4, 0.1), 0.3))
+    s.setSamplesPerPixel(spp)
+    s.setMaxBounceDepth(depth)
+    s.setDenoiserEnabled(False)
+    s.setBloomEnabled(False)
+    s.initBlueNoise()
+    s.uploadToGPU()
+    s.reset_rng(P.DEFAULT_SEED)
+    s.set_option("count_rays", 1)
+    import ctypes
+    md = ctypes.cast(s.flatten(), ctypes.POINTER(P.SceneDesc)).contents.meshes[blob]
+    base = np.ctypeslib.as_array(ctypes.cast(md.verts, ctypes.POINTER(ctypes.c_float)), (md.vert_count, 3)).copy()
+    rng = O.xorwow_init(P.DEFAULT_SEED, 0, W * H)
+    for f in range(3):
+        if f:
+            v = base * np.float32(1.0 + 0.4 * f) + np.array([0.6 * f, -0.3 * f, -4.0 - f], np.float32)
+            s.setVertices(blob, v.astype(np.float32))
+            (s.rebuildObjectChanges if rebuild else s.refitObjectChanges)()
+        fc = s.getFrameCount()
+        rgb = s.render_to_host()
+        g = dict(accum=s.read(P.BUF_ACCUM), normal=s.read(P.BUF_NORMAL), depth=s.read(P.BUF_DEPTH),
+                 object_id=s.read(P.BUF_OBJECT_ID), rgb8=rgb, rng=s.read(P.BUF_RNG), stats=s.stats())
+        c = O.render(s.flatten(), W, H, spp, depth, fc, blue_noise, rng, threads=8)
+        c["rgb8"] = O.tonemap(c["accum"], W, H, threads=8)
+        c["rng"] = rng.copy()
+        assert_frames_equal([g], [c])
+    assert (g["object_id"] == blob).sum() > 20
+    s.close()

@@ -68,7 +68,7 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     // PMODE 2 and 3 (the modes with a stack) pack them in 16 bits; PMODE 3 holds one TLAS leaf per ray at a time
     p += tlas_leaf ? (size_t)tlas_leaf * 128 : (size_t)meshes * (stack_entries ? 128 : 256);
     l.ray = (float *)p;
-    p += 6 * 256;
+    p += stack_entries ? 0 : 6 * 256; // (PMODE 1 only)
     l.occ = (uint32_t *)p;
     p += 256;
     l.stack = (uint2 *)p;
@@ -131,12 +131,14 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
     const RayO w = make_ray(o, d);
     float tE;
     alive = alive && slab(tlas_bmin(K), tlas_bmax(K), w, ANY ? tMax : T_FAR, tE);
-    L.ray[0 * 64 + lane] = o.x;
-    L.ray[1 * 64 + lane] = o.y;
-    L.ray[2 * 64 + lane] = o.z;
-    L.ray[3 * 64 + lane] = d.x;
-    L.ray[4 * 64 + lane] = d.y;
-    L.ray[5 * 64 + lane] = d.z;
+    if (!SHORT) { // PMODE 1 hands the rays over through LDS; the queue modes take them from the owner lane's registers
+        L.ray[0 * 64 + lane] = o.x;
+        L.ray[1 * 64 + lane] = o.y;
+        L.ray[2 * 64 + lane] = o.z;
+        L.ray[3 * 64 + lane] = d.x;
+        L.ray[4 * 64 + lane] = d.y;
+        L.ray[5 * 64 + lane] = d.z;
+    }
     if (ANY)
         L.occ[lane] = 0u;
     else
@@ -172,6 +174,19 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
 PT_DEV void pair_ray(const KParams &K, const PairLds &L, int r, const int4 mt, f3 &o, f3 &d, float &dirScale) {
     o = mk3(L.ray[r], L.ray[64 + r], L.ray[128 + r]);
     d = mk3(L.ray[192 + r], L.ray[256 + r], L.ray[320 + r]);
+    dirScale = 1.0f;
+    if (mt.z & 1) {
+        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
+        const f3 lo = xform_point(rec[2], rec[3], rec[4], o);
+        const f3 ld = xform_dir(rec[2], rec[3], rec[4], d);
+        dirScale = length(ld);
+        o = lo;
+        d = normalize(ld);
+    }
+}
+
+// the same from a world ray already in registers (queue modes: fetched from the owner lane by ds_bpermute)
+PT_DEV void pair_ray_from(const KParams &K, const int4 mt, f3 &o, f3 &d, float &dirScale) {
     dirScale = 1.0f;
     if (mt.z & 1) {
         const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
@@ -332,7 +347,7 @@ template <bool GEN> PT_DEV int4 pair_mesh(const KParams &K, const PairLds &L, in
 }
 
 // drains the pair queue [0, P): afterwards L.best[r] = min over ray r's pairs of {t bits, order << 24 | slot}
-template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P) {
+template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
     LdsStack stk{L.stack + lane};
     int next = 0;
     bool busy = false, active = false, xf = false;
@@ -360,13 +375,18 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
         const int n_idle = __builtin_popcountll(idle);
         if (next < P && (n_idle >= K.fetch_min || n_idle == 64)) {
             const int p = next + lane_prefix(idle);
-            if (!busy && p < P) {
-                const uint32_t e = ((const uint16_t *)L.pairs)[p];
-                r = (int)(e & 63u);
+            const bool take = !busy && p < P;
+            const uint32_t e = ((const uint16_t *)L.pairs)[take ? p : 0];
+            // the pair's ray lives in the registers of lane e & 63: every lane executes the shuffles (a source
+            // lane must be active for ds_bpermute), the takers keep the result -- no ray planes in LDS
+            const int src = (int)(e & 63u);
+            f3 po = mk3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+            f3 pd = mk3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+            if (take) {
+                r = src;
                 oi = (int)(e >> 6);
                 const int4 mt = pair_mesh<GEN>(K, L, r, oi);
-                f3 po, pd;
-                pair_ray(K, L, r, mt, po, pd, dirScale);
+                pair_ray_from(K, mt, po, pd, dirScale);
                 pr = make_ray(po, pd);
                 xf = (mt.z & 1) != 0;
                 cur = mt.x;
@@ -527,7 +547,7 @@ PT_DEV float winner_t_local(const KParams &K, int mesh, int slot, f3 o, f3 d) {
 PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
     const int P = build_pairs<false, true>(K, L, lane, alive, o, d, T_FAR);
     __syncthreads();
-    run_closest_queue<false>(K, L, lane, P);
+    run_closest_queue<false>(K, L, lane, P, o, d);
     __syncthreads();
     const unsigned long long key = L.best[lane];
     __syncthreads();
@@ -552,7 +572,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
 // Any hit, same queue.  A pair whose ray is already known to be occluded is dropped at refill (the
 // answer is an OR over the ray's pairs).
 // drains the pair queue [0, P): afterwards L.occ[r] != 0 for every ray r one of whose pairs found a hit
-template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L, int lane, int P) {
+template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
     LdsStack stk{L.stack + lane};
     const float *tmaxv = (const float *)L.best;
     int next = 0;
@@ -576,14 +596,17 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
         const int n_idle = __builtin_popcountll(idle);
         if (next < P && (n_idle >= K.fetch_min || n_idle == 64)) {
             const int p = next + lane_prefix(idle);
-            if (!busy && p < P) {
-                const uint32_t e = ((const uint16_t *)L.pairs)[p];
-                r = (int)(e & 63u);
+            const bool take = !busy && p < P;
+            const uint32_t e = ((const uint16_t *)L.pairs)[take ? p : 0];
+            const int src = (int)(e & 63u); // the ray comes out of its owner lane's registers, see run_closest_queue
+            f3 po = mk3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+            f3 pd = mk3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+            if (take) {
+                r = src;
                 if (L.occ[r] == 0u) {
                     const int4 mt = pair_mesh<GEN>(K, L, r, (int)(e >> 6));
-                    f3 po, pd;
                     float dirScale;
-                    pair_ray(K, L, r, mt, po, pd, dirScale);
+                    pair_ray_from(K, mt, po, pd, dirScale);
                     pr = make_ray(po, pd);
                     tm = tmaxv[r];
                     if (mt.z & 1)
@@ -753,7 +776,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
     const int P = build_pairs<true, true>(K, L, lane, alive, o, d, tMax);
     ((float *)L.best)[lane] = tMax;
     __syncthreads();
-    run_any_queue<false>(K, L, lane, P);
+    run_any_queue<false>(K, L, lane, P, o, d);
     __syncthreads();
     const bool occluded = alive && (L.occ[lane] != 0u);
     __syncthreads();
@@ -805,12 +828,6 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
     const RayO w = make_ray(o, d);
     float tE;
     bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, T_FAR, tE);
-    L.ray[0 * 64 + lane] = o.x;
-    L.ray[1 * 64 + lane] = o.y;
-    L.ray[2 * 64 + lane] = o.z;
-    L.ray[3 * 64 + lane] = d.x;
-    L.ray[4 * 64 + lane] = d.y;
-    L.ray[5 * 64 + lane] = d.z;
     Hit best;
     best.t = best.t_local = T_FAR;
     best.u = best.v = 0.0f;
@@ -862,7 +879,7 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
             break;
         const int P = build_pairs_general<false>(K, L, lane, has, lf, w, T_FAR);
         __syncthreads();
-        run_closest_queue<true>(K, L, lane, P);
+        run_closest_queue<true>(K, L, lane, P, o, d);
         __syncthreads();
         const unsigned long long key = L.best[lane];
         __syncthreads();
@@ -885,12 +902,6 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
     const RayO w = make_ray(o, d);
     float tE;
     bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, tMax, tE);
-    L.ray[0 * 64 + lane] = o.x;
-    L.ray[1 * 64 + lane] = o.y;
-    L.ray[2 * 64 + lane] = o.z;
-    L.ray[3 * 64 + lane] = d.x;
-    L.ray[4 * 64 + lane] = d.y;
-    L.ray[5 * 64 + lane] = d.z;
     ((float *)L.best)[lane] = tMax;
     L.occ[lane] = 0u;
     int tcur = K.tlas_root_ref, tsp = 0;
@@ -936,7 +947,7 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
             break;
         const int P = build_pairs_general<true>(K, L, lane, has, lf, w, tMax);
         __syncthreads();
-        run_any_queue<true>(K, L, lane, P);
+        run_any_queue<true>(K, L, lane, P, o, d);
         __syncthreads();
         if (L.occ[lane] != 0u)
             t_active = need_pop = false; // blocked: nothing more to look for

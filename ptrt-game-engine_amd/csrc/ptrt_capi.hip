@@ -505,9 +505,10 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
 // triangle packets to fit a modest LDS budget
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
     if (pmode == 3) // no mesh table; pair list for one TLAS leaf per ray; TLAS stack + the rays' leaf starts
-        return (size_t)c->tlas_max_leaf * 128 + 6 * 256 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) +
+        return (size_t)c->tlas_max_leaf * 128 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) +
                (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 + 256 + pt::LEAF_PAIR_BYTES;
-    const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * (pmode == 1 ? 256 : 128) + 6 * 256 + 512 + 256;
+    const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * (pmode == 1 ? 256 : 128) +
+                          (pmode == 1 ? 6 * 256 : 0) + 512 + 256; // (ray planes: PMODE 1 only)
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
 }

@@ -59,6 +59,14 @@ def test_moving_instances_take_the_fast_path_and_match_the_oracle(P, O, blue_noi
         assert_frames_equal([g], [c])
         assert (g["object_id"] == cube).sum() > 20, f
     assert _counts(P, s) == (1, 3)      # one full upload, three transform-only updates
+    # a different mesh count is refused (that is a geometry change) and nothing is uploaded
+    d = C.cast(s.flatten(), C.POINTER(P.SceneDesc)).contents
+    P.lib.ptrt_update_instances.argtypes = [C.c_void_p, C.POINTER(P.MeshDesc), C.c_int, C.POINTER(P.BvhNode), C.c_int,
+                                            C.POINTER(C.c_int32), C.c_int]
+    assert P.lib.ptrt_update_instances(s.ctx, d.meshes, d.mesh_count - 1, d.tlas_nodes, d.tlas_node_count,
+                                       d.tlas_mesh_indices, d.tlas_index_count) == -1
+    assert b"use ptrt_upload_geometry" in P.lib.ptrt_last_error(s.ctx)
+    assert _counts(P, s) == (1, 3)
     # a vertex change still takes the full path
     s.scale(cube, (1.1, 1.0, 1.0))
     s.commitObjectChanges()

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Soak check (GPU box, repo root): 24 consecutive 1080p frames with a wandering camera on four scenes, rendered
+by the default traversal, by the plain one (batches of 64 pairs, every lane its own leaf, no stealing, no yield,
+one lane per pair) and by the lock-step mesh loop; every frame's HDR image, object ids, generator states and ray
+counts must be identical.  (tests/test_misc_gpu.py holds the two-frame version with the async and wavefront
+kernels; this one is for more rays.)"""
+import sys, os
+sys.path.insert(0, "ptrt-game-engine_amd"); sys.path.insert(0, "tests")
+import numpy as np, torch
+import ptrt_amd as P
+from test_parity_gpu import _many_meshes
+def frames(build, opts, n, spp):
+    s = P.Scene(1920, 1080); build(s)
+    s.setSamplesPerPixel(spp); s.setMaxBounceDepth(4); s.setDenoiserEnabled(False); s.setBloomEnabled(False)
+    s.initBlueNoise(); s.uploadToGPU(); s.set_option("count_rays", 1)
+    for k, v in opts.items(): s.set_option(k, v)
+    out = []
+    for f in range(n):
+        if f % 5 == 4: s.moveCamera((0.3 * (f % 7) - 1.0, 0.2 * (f % 3), 5.0 - 0.1 * f))
+        s.render_to_host()
+        out.append((s.read(P.BUF_ACCUM).view(np.uint32).copy(), s.read(P.BUF_OBJECT_ID).copy(), s.read(P.BUF_RNG).copy(), s.stats()))
+    s.close(); return out
+plain = dict(fetch_min=0, leaf_pairs=0, steal=0, leaf_min=64, pair_split=0)
+for name, build, spp in (("showcase", P.scenes.showcase, 4), ("fluid", lambda s: P.scenes.fluid(s, cells=256, t=0.7), 2),
+                         ("many", lambda s: _many_meshes(P, s, n=60), 4), ("cornell", P.scenes.cornell, 4)):
+    a = frames(build, {}, 24, spp); b = frames(build, plain, 24, spp); c = frames(build, dict(pair_trace=0), 24, spp)
+    bad = 0
+    for f, (x, y, z) in enumerate(zip(a, b, c)):
+        for k in range(3):
+            if not (np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k])): bad += 1
+        if not (x[3] == y[3] == z[3]): bad += 1
+    print(name, "24 frames x 3 variants:", "IDENTICAL" if bad == 0 else f"{bad} MISMATCHES", a[-1][3])

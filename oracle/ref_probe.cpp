@@ -6,7 +6,7 @@
 //   common/bluenoise.cuh:79-177   BlueNoiseGenerator::generateBlueNoise2D  (the 64x64x2 table)
 //   pathtracer/rendering/taa.cuh:19-61   Halton-16 table + getTAAJitter
 //   pathtracer/scene/lights.cuh:12-22    Light (layout the C ABI's ptrt_light mirrors)
-//   common/vec3.cuh, common/ray.cuh      vec3 / Ray layout
+//   common/vec3.cuh, common/ray.cuh      vec3 / Ray layout, vec3's host-side arithmetic (known answers)
 //
 // Everything else on the path includes <curand_kernel.h> (pathtracer/math/mathutils.cuh:11, pulled
 // in by common/mat4.cuh:6), which the image lacks, so it is unbuildable here and stays
@@ -62,7 +62,25 @@ int main(int argc, char **argv) {
            (int)L.type, bits(L.position.x), bits(L.position.y), bits(L.position.z), bits(L.direction.x),
            bits(L.direction.y), bits(L.direction.z), bits(L.color.x), bits(L.color.y), bits(L.color.z),
            bits(L.intensity), bits(L.range), bits(L.innerCone), bits(L.outerCone), bits(L.radius));
-    printf(" \"light_types\": {\"LIGHT_POINT\": %d, \"LIGHT_DIRECTIONAL\": %d, \"LIGHT_SPOT\": %d}\n}\n",
+    printf(" \"light_types\": {\"LIGHT_POINT\": %d, \"LIGHT_DIRECTIONAL\": %d, \"LIGHT_SPOT\": %d},\n",
            (int)LIGHT_POINT, (int)LIGHT_DIRECTIONAL, (int)LIGHT_SPOT);
+    // common/vec3.cuh:99-157 as the HOST compiler sees it (the arithmetic the scene-building code runs in:
+    // Scene::add*, transforms, the camera frame): 48 seeded input pairs, results as bit patterns.  The kernels'
+    // device arithmetic (nvcc's fmad contraction) is a different matter and is NOT what this pins.
+    printf(" \"vec3_kat\": [");
+    uint32_t st = 12345u;
+    auto rnd = [&]() { // LCG -> floats in (-4, 4)
+        st = st * 1664525u + 1013904223u;
+        return ((float)(st >> 8) / 16777216.0f - 0.5f) * 8.0f;
+    };
+    for (int k = 0; k < 48; ++k) {
+        const float ax = rnd(), ay = rnd(), az = rnd(), bx = rnd(), by = rnd(), bz = rnd(), t = rnd(); // (in this order)
+        const vec3 a(ax, ay, az), b(bx, by, bz);
+        const vec3 c = cross(a, b), n = b.normalized(), r = normalize(a - b), l = lerp(a, b, 0.5f + 0.1f * t), q = a * b + t * a - b / 3.0f;
+        printf("%s[%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u]", k ? "," : "", bits(dot(a, b)), bits(a.length()),
+               bits(a.length_squared()), bits(c.x), bits(c.y), bits(c.z), bits(n.x), bits(n.y), bits(n.z), bits(r.x), bits(r.y),
+               bits(r.z), bits(l.x), bits(l.y), bits(l.z), bits(q.x), bits(q.y), bits(q.z));
+    }
+    printf("]\n}\n");
     return 0;
 }

@@ -118,6 +118,38 @@ def test_real_tlas_many_meshes(P, O, blue_noise, pair_trace, leaf):
     s.close()
 
 
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (8, 8), (9, 17)])
+def test_tiny_and_ragged_frames(P, O, blue_noise, size):
+    """Frames smaller than one 8x8 tile and frames whose edges cut tiles."""
+    for build in (P.scenes.cornell, lambda s: P.scenes.showcase(s, segments=6)):
+        s = P.Scene(*size)
+        build(s)
+        gpu, cpu = render_both(P, O, s, blue_noise, 2, 3, 2)
+        assert_frames_equal(gpu, cpu)
+        s.close()
+
+
+def test_maximum_samples_and_bounces(P, O, blue_noise):
+    """samplesPerPixel and maxBounceDepth at the setters' upper clamp (16, scene.cuh:1894-1897), a scene without
+    lights (no light sampling at all) and one without sky."""
+    s = P.Scene(24, 16)
+    P.scenes.showcase(s, segments=8)
+    gpu, cpu = render_both(P, O, s, blue_noise, 16, 16, 1)
+    assert_frames_equal(gpu, cpu)
+    assert gpu[0]["stats"]["paths"] == 24 * 16 * 16
+    s.close()
+    s = P.Scene(40, 32)
+    for k in range(3):
+        m = s.addCube(P.Material((0.8, 0.3 + 0.2 * k, 0.2), 0.4, emission=(2.0, 2.0, 2.0) if k == 1 else (0.0, 0.0, 0.0)))
+        s.scale(m, (1.0 + k, 1.0, 1.0))
+        s.moveTo(m, (-3.0 + 3.0 * k, -1.0 + k, -6.0))
+    s.disableSky()
+    gpu, cpu = render_both(P, O, s, blue_noise, 3, 5, 2)   # no lights were added
+    assert_frames_equal(gpu, cpu)
+    assert gpu[0]["stats"]["shadow_rays"] == 0 and gpu[0]["accum"].any()
+    s.close()
+
+
 def test_cornell_quads(P, O, blue_noise):
     s = P.Scene(64, 64)
     P.scenes.cornell(s, quads=True)

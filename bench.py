@@ -31,6 +31,8 @@ def build_scene(P, name, W, H, y0, rows, device):
         P.scenes.cornell(s)
     elif name == "showcase":
         P.scenes.showcase(s)
+    elif name == "many":  # 128 spheres/cubes of 2 x 32^2 triangles behind a real TLAS (not a BASELINE config)
+        P.scenes.many(s, 128, sphere_segments=32)
     elif name == "fluid":
         s.water_mesh, _ = P.scenes.fluid(s, cells=256, t=0.0)
     else:

@@ -9,6 +9,8 @@
                    at the scene-8 positions with the scene-8 materials, lights and camera,
                    plus an addPlaneXZ floor.
   fluid(scene, t)  dynamic height-field "water" over a static sphere "ship" (config 5).
+  many(scene, n)   Cornell box + n small cubes and spheres, every third an instance with its own transform:
+                   more meshes than one TLAS leaf holds (17), i.e. a TLAS with inner nodes.
 """
 import math
 
@@ -135,3 +137,22 @@ def fluid(scene, cells=256, t=0.0, ship_segments=100):
     scene.addDirectionalLight((-0.4, -1.0, -0.3), (1.0, 0.96, 0.9), 3.0)
     scene.setCamera((0.0, 6.0, 18.0), (0.0, 0.0, 0.0), (0, 1, 0), 45.0)
     return w, ship
+
+
+def many(scene, n=40, instanced=True, sphere_segments=5):
+    """Cornell box + n small cubes and spheres (every third an instance with its own transform, every seventh
+    transmissive): more meshes than a TLAS leaf holds, so the TLAS is a real tree."""
+    cornell(scene)
+    rs = np.random.RandomState(3)
+    for k in range(n):
+        mat = Material(tuple(rs.uniform(0.2, 0.9, 3)), float(rs.uniform(0.05, 0.8)), float(k % 4 == 0),
+                       transmission=1.0 if k % 7 == 3 else 0.0, ior=1.4)
+        m = scene.addSphere(sphere_segments, mat) if k % 2 else scene.addCube(mat)
+        pos = (float(rs.uniform(-4, 4)), float(rs.uniform(-4.5, 3.5)), float(rs.uniform(-9, -2)))
+        if instanced and k % 3 == 0:
+            scene.setPosition(m, pos)
+            scene.setRotation(m, tuple(rs.uniform(-1, 1, 3)))
+            scene.setInstanceScale(m, tuple(rs.uniform(0.2, 0.5, 3)))
+        else:
+            scene.scale(m, tuple(rs.uniform(0.2, 0.5, 3)))
+            scene.moveTo(m, pos)

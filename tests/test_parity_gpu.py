@@ -85,22 +85,7 @@ def test_cornell_one_lane_per_pair(P, O, blue_noise):
 
 
 def _many_meshes(P, s, n=40, instanced=True):
-    """Cornell box + n small cubes and spheres (every third an instance with its own transform): more meshes than a
-    TLAS leaf holds, so the TLAS is a real tree."""
-    P.scenes.cornell(s)
-    rs = np.random.RandomState(3)
-    for k in range(n):
-        mat = P.Material(tuple(rs.uniform(0.2, 0.9, 3)), float(rs.uniform(0.05, 0.8)), float(k % 4 == 0),
-                         transmission=1.0 if k % 7 == 3 else 0.0, ior=1.4)
-        m = s.addSphere(5, mat) if k % 2 else s.addCube(mat)
-        pos = (float(rs.uniform(-4, 4)), float(rs.uniform(-4.5, 3.5)), float(rs.uniform(-9, -2)))
-        if instanced and k % 3 == 0:
-            s.setPosition(m, pos)
-            s.setRotation(m, tuple(rs.uniform(-1, 1, 3)))
-            s.setInstanceScale(m, tuple(rs.uniform(0.2, 0.5, 3)))
-        else:
-            s.scale(m, tuple(rs.uniform(0.2, 0.5, 3)))
-            s.moveTo(m, pos)
+    P.scenes.many(s, n, instanced)
 
 
 @pytest.mark.parametrize("pair_trace,leaf", [(1, None), (0, None), (1, (2, 0)), (1, (4, 1))])

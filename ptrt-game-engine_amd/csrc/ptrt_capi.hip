@@ -458,7 +458,9 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.tlas_depth = c->tlas_depth < 1 ? 1 : c->tlas_depth;
     K.pair_split = (c->pair_split && !c->any_transform) ? 1 : 0;
     K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
-    K.leaf_pairs = c->leaf_pairs;
+    // the compacted leaf phase lists up to 64 x (largest leaf) tests in LEAF_PAIR_BYTES - 512 bytes of LDS: the reference
+    // builder's leaves (<= 17 triangles) fit; a scene built with a larger leaf target walks its leaves lane by lane
+    K.leaf_pairs = (c->leaf_pairs && (size_t)c->pair_max_leaf * 64 <= (size_t)pt::LEAF_PAIR_BYTES - 512) ? 1 : 0;
     K.leaf_min = c->leaf_min;
     K.steal = c->steal;
     K.cam = c->cam;
@@ -601,6 +603,8 @@ int run_wavefront(ptrt_ctx *c, const pt::KParams &K, bool full, int spp, int max
 // ---- asynchronous-lane megakernel -------------------------------------------------------------
 bool async_applicable(const ptrt_ctx *c) {
     if (!c->async_lanes || !c->tlas_single_leaf || c->pair_meshes <= 0 || c->pair_meshes > 64)
+        return false;
+    if ((size_t)c->pair_max_leaf * 64 > (size_t)pt::LEAF_PAIR_BYTES - 512) // its leaf phase is always the compacted one
         return false;
     return ((size_t)c->stack_entries * 64 + pt::AS_RING / 2) * sizeof(uint2) + pt::LEAF_PAIR_BYTES <= 40 * 1024;
 }

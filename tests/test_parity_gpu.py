@@ -135,6 +135,22 @@ def test_maximum_samples_and_bounces(P, O, blue_noise):
     s.close()
 
 
+def test_large_leaf_target(P, O, blue_noise):
+    """A leaf target beyond the reference's default (12 + 5): leaves of up to 40 triangles do not fit the compacted
+    leaf phase's test list, so the kernel walks them lane by lane -- same bits."""
+    s = P.Scene(80, 56)
+    P.scenes.showcase(s, segments=10)
+    s.setBVHLeafTarget(30, 10)
+    gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 1)
+    assert_frames_equal(gpu, cpu)
+    s.set_option("async_lanes", 1)          # refused for such leaves: falls back to the default kernel
+    s.render_to_host()
+    import ctypes
+    P.lib.ptrt_debug_last_render_mode.argtypes = [ctypes.c_void_p]
+    assert P.lib.ptrt_debug_last_render_mode(s.ctx) == 0
+    s.close()
+
+
 def test_cornell_quads(P, O, blue_noise):
     s = P.Scene(64, 64)
     P.scenes.cornell(s, quads=True)

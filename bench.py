@@ -48,7 +48,7 @@ def cpu_baseline(P, scene_name, W, H, spp, depth, frame, threads):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     s = build_scene(P, scene_name, W, H, 0, 0, P.HOST_ONLY)
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     desc = s.flatten()
     rows = H if scene_name == "cornell" else max(8, H // 4)
@@ -117,7 +117,7 @@ def main():
     W, H = args.width, args.height
     y0, rows = tilefarm.bands(H, world)[rank]  # horizontal bands; the last rank takes the remainder rows
     scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, dev_index)
-    scene.setSamplesPerPixel(args.spp)
+    scene.setPerfSamplesPerPixel(args.spp)
     scene.setMaxBounceDepth(args.depth)
     post_on_rank0 = world > 1 and (args.denoise or args.bloom)
     if world == 1:
@@ -154,7 +154,7 @@ def main():
             gband_host = None
         if rank == 0:
             presenter = build_scene(P, args.scene, W, H, 0, 0, dev_index)
-            presenter.setSamplesPerPixel(args.spp)
+            presenter.setPerfSamplesPerPixel(args.spp)
             presenter.setMaxBounceDepth(args.depth)
             presenter.setDenoiserEnabled(args.denoise)
             presenter.setBloomEnabled(args.bloom)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTRT_ABI_VERSION 3 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height; 3: + ptrt_post_frame, ptrt_update_instances (additions only) */
+#define PTRT_ABI_VERSION 4 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height; 3: + ptrt_post_frame, ptrt_update_instances; 4: + ptrt_ring_*, ptrt_farm_* (additions only) */
 
 enum {
     PTRT_OK = 0,
@@ -339,6 +339,24 @@ int ptrt_present_map(ptrt_ctx *ctx, int slot, void **device_pixels);
 int ptrt_present_unmap(ptrt_ctx *ctx, int slot);
 int ptrt_present_acquire(ptrt_ctx *ctx, int slot, const unsigned char **host_pixels);
 int ptrt_present_destroy(ptrt_ctx *ctx);
+
+/* The same ring WITHOUT a context: what rtgl::init_interop_viewer(V, width, height, title, cudaDevice)
+ * (glfw_view_interop.hpp:174-279) creates before any Scene exists -- the GL pixel-buffer object registered with
+ * CUDA becomes `slots` device frames of `frame_bytes` on `device`, each mirrored into pinned host memory.
+ *   ptrt_ring_map     = cudaGraphicsMapResources + GetMappedPointer (glfw_view_interop.hpp:281-298)
+ *   ptrt_ring_unmap   = cudaGraphicsUnmapResources (:300-307): enqueues the device->host copy behind the frame.
+ *                       ptrt_render / ptrt_post_frame recognise a ring slot as their out_rgb8 and record the
+ *                       slot's event on THEIR stream, so the copy waits for exactly that frame and the call site
+ *                       stays `map -> scene.render_to_device(ptr) -> unmap`; a slot written by anything else is
+ *                       ordered behind all work submitted to the device's blocking streams (NULL-stream event).
+ *   ptrt_ring_acquire = what blit_pbo_to_texture (:309-317) needs: waits for the copy, returns the host pixels.
+ * Errors: ptrt_last_error(NULL). */
+typedef struct ptrt_ring ptrt_ring;
+int ptrt_ring_create(int device, size_t frame_bytes, int slots, ptrt_ring **out);
+int ptrt_ring_map(ptrt_ring *ring, int slot, void **device_pixels);
+int ptrt_ring_unmap(ptrt_ring *ring, int slot);
+int ptrt_ring_acquire(ptrt_ring *ring, int slot, const unsigned char **host_pixels);
+void ptrt_ring_destroy(ptrt_ring *ring);
 
 /* convenience: the five uploads above from one flattened description */
 int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);

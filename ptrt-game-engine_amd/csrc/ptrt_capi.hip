@@ -155,8 +155,40 @@ struct ptrt_ctx {
     bool timed = false;
 };
 
+// Presentation ring without a context (ptrt_ring_*): the CUDA-registered GL pixel-buffer object of
+// rtgl::init_interop_viewer as `slots` device frames mirrored into pinned host memory.
+struct ptrt_ring {
+    int device = 0;
+    size_t bytes = 0;
+    struct Slot {
+        unsigned char *dev = nullptr, *host = nullptr;
+        hipEvent_t rendered = nullptr, done = nullptr;
+        bool in_flight = false; // a download of this slot has been enqueued and not yet waited for
+        bool marked = false;    // `rendered` was recorded by the render call that wrote the slot
+    };
+    std::vector<Slot> slots;
+    hipStream_t copy_stream = nullptr;
+};
+
 namespace {
 
+std::mutex g_ring_mutex;
+std::set<ptrt_ring *> g_rings;
+
+// ptrt_render / ptrt_post_frame wrote their RGB8 frame to `out` on `stream`: if that is a ring slot, the slot's
+// download must wait for exactly this point of the stream.
+void ring_mark_rendered(const void *out, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    for (ptrt_ring *r : g_rings)
+        for (auto &s : r->slots)
+            if (s.dev == out) {
+                s.marked = hipEventRecord(s.rendered, stream) == hipSuccess;
+                return;
+            }
+}
+
+// Records the message for ptrt_last_error.  `c` may be a stale (already destroyed) handle -- every entry point
+// reports "bad context" through here -- so it is only written to while it is in the live set.
 int fail(ptrt_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -164,8 +196,11 @@ int fail(ptrt_ctx *c, int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_last_error = buf;
-    if (c)
-        c->err = buf;
+    if (c) {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        if (g_live.count(c))
+            c->err = buf;
+    }
     return code;
 }
 
@@ -219,13 +254,14 @@ void gf2_square(GF2 &m) {
         gf2_apply(m, m.col[j], t.col[j]);
     m = t;
 }
-// jump[k] = (one generator step)^(2^(67+k)), k = 0..n-1, as 800 words each
-const std::vector<uint32_t> &jump_matrices(int n) {
+// jump[k] = (one generator step)^(2^(67+k)), k = 0..JUMP_MAX-1, as 800 words each.  Computed once for the largest
+// pixel index a context can have (2^40 pixels), so the vector never reallocates under a concurrent reader.
+constexpr int JUMP_MAX = 40;
+const std::vector<uint32_t> &jump_matrices() {
     static std::vector<uint32_t> out;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if ((int)out.size() >= n * 800)
-        return out;
+    static std::once_flag once;
+    std::call_once(once, [] {
+    const int n = JUMP_MAX;
     GF2 m;
     for (int j = 0; j < 160; ++j) { // image of basis vector j under one step of the recurrence
         uint32_t v[5] = {0, 0, 0, 0, 0};
@@ -241,6 +277,7 @@ const std::vector<uint32_t> &jump_matrices(int n) {
         std::memcpy(&out[(size_t)k * 800], m.col, 800 * sizeof(uint32_t));
         gf2_square(m);
     }
+    });
     return out;
 }
 
@@ -1031,7 +1068,9 @@ int ptrt_reset_rng(ptrt_ctx *c, unsigned long long seed) {
     while ((last >> bits) != 0)
         ++bits;
     if (bits > c->n_jump) {
-        const std::vector<uint32_t> &J = jump_matrices(bits);
+        if (bits > JUMP_MAX)
+            return fail(c, PTRT_E_INVALID, "ptrt_reset_rng: frame of 2^%d pixels (at most 2^%d)", bits, JUMP_MAX);
+        const std::vector<uint32_t> &J = jump_matrices();
         dfree(c->d_jump);
         HIP_TRY(c, hipMalloc((void **)&c->d_jump, (size_t)bits * 800 * sizeof(uint32_t)));
         HIP_TRY(c, hipMemcpy(c->d_jump, J.data(), (size_t)bits * 800 * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1168,6 +1207,10 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
         return rc;
 
     free_scene(c);
+    // nothing of the old scene is left: until the last upload below has succeeded the context has no geometry,
+    // so a failure in between (hipMalloc) leaves it answering PTRT_E_NOT_READY instead of launching on NULL arenas
+    c->have_geometry = false;
+    c->n_slots = c->n_leaves = 0;
     c->n_meshes = mesh_count;
     c->h_mesh_recs = recs;
     if (int rc = push_mesh_recs(c, true))
@@ -1730,6 +1773,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                            c->d_accum, current, c->W, c->H, c->rw, c->rh, frame_rgb8);
         HIP_TRY(c, hipGetLastError());
     }
+    if (out_rgb8 && out_is_device)
+        ring_mark_rendered(out_rgb8, c->stream);
     if (out_rgb8 && !out_is_device) {
         HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1772,6 +1817,8 @@ int ptrt_post_frame(ptrt_ctx *c, const float *accum, const float *normal, const 
         if (int rc = run_bloom(c, current, c->rw, c->rh, frame_rgb8))
             return rc;
     }
+    if (out_rgb8 && out_is_device)
+        ring_mark_rendered(out_rgb8, c->stream);
     if (out_rgb8 && !out_is_device) {
         HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1860,6 +1907,132 @@ int ptrt_present_acquire(ptrt_ctx *c, int slot, const unsigned char **host_pixel
     }
     *host_pixels = s.host;
     return PTRT_OK;
+}
+
+namespace {
+bool ring_live(ptrt_ring *r) {
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    return r && g_rings.count(r);
+}
+void ring_free(ptrt_ring *r) {
+    (void)hipSetDevice(r->device);
+    if (r->copy_stream) {
+        (void)hipStreamSynchronize(r->copy_stream);
+        (void)hipStreamDestroy(r->copy_stream);
+    }
+    for (auto &s : r->slots) {
+        if (s.dev)
+            (void)hipFree(s.dev);
+        if (s.host)
+            (void)hipHostFree(s.host);
+        if (s.rendered)
+            (void)hipEventDestroy(s.rendered);
+        if (s.done)
+            (void)hipEventDestroy(s.done);
+    }
+    delete r;
+}
+} // namespace
+
+int ptrt_ring_create(int device, size_t frame_bytes, int slots, ptrt_ring **out) {
+    if (!out)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_ring_create: out is NULL");
+    *out = nullptr;
+    if (frame_bytes == 0 || slots < 1 || slots > 8)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_ring_create: %zu bytes, %d slots (1..8)", frame_bytes, slots);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PTRT_E_NO_DEVICE, "no HIP device available; this library has no CPU path");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, PTRT_E_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    ptrt_ring *r = new ptrt_ring;
+    r->device = device;
+    r->bytes = frame_bytes;
+    r->slots.resize((size_t)slots);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking);
+    for (auto &s : r->slots) {
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&s.dev, frame_bytes);
+        if (e == hipSuccess)
+            e = hipHostMalloc((void **)&s.host, frame_bytes, hipHostMallocDefault);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        ring_free(r);
+        return fail(nullptr, PTRT_E_HIP, "ptrt_ring_create: %s", hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        g_rings.insert(r);
+    }
+    *out = r;
+    return PTRT_OK;
+}
+
+int ptrt_ring_map(ptrt_ring *r, int slot, void **device_pixels) {
+    if (!ring_live(r) || !device_pixels || slot < 0 || slot >= (int)r->slots.size())
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_ring_map: bad ring or slot");
+    HIP_TRY(nullptr, hipSetDevice(r->device));
+    auto &s = r->slots[(size_t)slot];
+    if (s.in_flight) { // the frame about to be overwritten must have reached the host
+        HIP_TRY(nullptr, hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        s.marked = false;
+    }
+    *device_pixels = s.dev;
+    return PTRT_OK;
+}
+
+int ptrt_ring_unmap(ptrt_ring *r, int slot) {
+    if (!ring_live(r) || slot < 0 || slot >= (int)r->slots.size())
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_ring_unmap: bad ring or slot");
+    HIP_TRY(nullptr, hipSetDevice(r->device));
+    auto &s = r->slots[(size_t)slot];
+    bool marked;
+    {
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        marked = s.marked;
+    }
+    // a slot not written through ptrt_render: behind everything already submitted to the device's blocking
+    // streams, which is what cudaGraphicsUnmapResources guarantees the GL side
+    if (!marked)
+        HIP_TRY(nullptr, hipEventRecord(s.rendered, nullptr));
+    HIP_TRY(nullptr, hipStreamWaitEvent(r->copy_stream, s.rendered, 0));
+    HIP_TRY(nullptr, hipMemcpyAsync(s.host, s.dev, r->bytes, hipMemcpyDeviceToHost, r->copy_stream));
+    HIP_TRY(nullptr, hipEventRecord(s.done, r->copy_stream));
+    s.in_flight = true;
+    return PTRT_OK;
+}
+
+int ptrt_ring_acquire(ptrt_ring *r, int slot, const unsigned char **host_pixels) {
+    if (!ring_live(r) || !host_pixels || slot < 0 || slot >= (int)r->slots.size())
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_ring_acquire: bad ring or slot");
+    HIP_TRY(nullptr, hipSetDevice(r->device));
+    auto &s = r->slots[(size_t)slot];
+    if (s.in_flight) {
+        HIP_TRY(nullptr, hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    *host_pixels = s.host;
+    return PTRT_OK;
+}
+
+void ptrt_ring_destroy(ptrt_ring *r) {
+    {
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        if (!r || !g_rings.count(r))
+            return;
+        g_rings.erase(r);
+    }
+    ring_free(r);
 }
 
 int ptrt_last_kernel_ms(ptrt_ctx *c, float *trace_ms, float *tonemap_ms) {

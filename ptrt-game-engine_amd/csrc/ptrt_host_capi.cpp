@@ -3,6 +3,7 @@
 // callers can drive the same host API a C++ application uses.  One function per
 // Scene method; C++ exceptions become negative return codes + hs_last_error().
 #include "../host/ptrt/scene.hpp"
+#include "../host/ptrt/serialize.hpp"
 #include "../host/ptrt/view.hpp"
 
 #include <chrono>
@@ -209,6 +210,9 @@ void hs_free_hdri(void *s) { static_cast<Scene *>(s)->freeHDRI(); }
 void hs_set_bvh_leaf_target(void *s, int target, int tol) { static_cast<Scene *>(s)->setBVHLeafTarget(target, tol); }
 void hs_set_max_bounce_depth(void *s, int d) { static_cast<Scene *>(s)->setMaxBounceDepth(d); }
 void hs_set_samples_per_pixel(void *s, int spp) { static_cast<Scene *>(s)->setSamplesPerPixel(spp); }
+void hs_set_perf_samples_per_pixel(void *s, int spp) { static_cast<Scene *>(s)->setPerfSamplesPerPixel(spp); }
+void hs_set_max_depth(void *s, int d) { static_cast<Scene *>(s)->setMaxDepth(d); }
+int hs_get_samples_per_pixel(void *s) { return static_cast<Scene *>(s)->getSamplesPerPixel(); }
 int hs_set_denoiser_enabled(void *s, int e) { HS_TRY(static_cast<Scene *>(s)->setDenoiserEnabled(e != 0)); return 0; }
 void hs_set_bloom_enabled(void *s, int e) { static_cast<Scene *>(s)->setBloomEnabled(e != 0); }
 int hs_set_performance_preset(void *s, const char *name) { HS_TRY(static_cast<Scene *>(s)->setPerformancePreset(name)); return 0; }
@@ -310,7 +314,7 @@ int hs_view_run(void *s, int frames, int slots, unsigned char *out_frames, doubl
         rtgl::init_interop_viewer(V, scene, "headless", slots);
         V.dump_prefix = dump_prefix ? dump_prefix : "";
         V.dump_every = dump_every;
-        const size_t bytes = scene.getPixelBufferSize();
+        const size_t bytes = (size_t)scene.getWidth() * scene.getTileRows() * 3; // a band context presents its rows
         size_t got = 0;
         auto present = [&](bool flush) {
             rtgl::blit_pbo_to_texture(V, flush);
@@ -348,6 +352,21 @@ const ptrt_scene_desc *hs_flatten(void *s) {
     } catch (const std::exception &e) {
         g_err = e.what();
         return nullptr;
+    }
+}
+
+
+// canonical byte stream of the flattened scene (host/ptrt/serialize.hpp); returns its length, copies
+// min(length, cap) bytes
+size_t hs_serialize_scene(void *s, unsigned char *out, size_t cap) {
+    try {
+        const std::vector<uint8_t> b = ptrt_detail::serialize_scene(static_cast<Scene *>(s)->flatten());
+        if (out && cap)
+            std::memcpy(out, b.data(), b.size() < cap ? b.size() : cap);
+        return b.size();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 0;
     }
 }
 

@@ -41,6 +41,16 @@ struct Material {
     }
 };
 
+// conversion helpers of material_lib.cuh:128-146, used by the applications' material libraries (app_utils.cuh:79-103)
+inline float phongShininessToRoughness(float n) {
+    const float alpha = sqrtf(2.0f / (fmaxf(n, 1.0f) + 2.0f));
+    return fminf(fmaxf(fmaxf(alpha, 0.02f), 0.0f), 1.0f);
+}
+inline float iorToF0(float ior) {
+    const float a = (ior - 1.0f) / (ior + 1.0f);
+    return a * a;
+}
+
 // ---- Light (scene/lights.cuh) ---------------------------------------------------------
 enum LightType { LIGHT_POINT = 0, LIGHT_DIRECTIONAL = 1, LIGHT_SPOT = 2 };
 struct Light {
@@ -100,6 +110,11 @@ class Camera {
         update_matrices(origin, vec3(0, 0, -1), vec3(0, 1, 0));
     }
     mat4 get_view_proj() const { return proj_matrix * view_matrix; } // camera.cuh:257-259
+    // get_ray_simple (camera.cuh:201-205); the debug-ray helper is the only host caller
+    void get_ray(float s, float t, vec3 &o, vec3 &d) const {
+        o = origin;
+        d = (lower_left_corner + s * horizontal + t * vertical - origin).normalized();
+    }
     vec3 get_origin() const { return origin; }
     vec3 get_lower_left_corner() const { return lower_left_corner; }
     vec3 get_horizontal() const { return horizontal; }
@@ -199,6 +214,10 @@ struct HitInfo { // math/intersection.cuh:108-124
 };
 
 // ---- Scene ----------------------------------------------------------------------------
+// device of `Scene(w, h)`; -1 = host-only scenes (build / flatten / inspect on a box without a GPU)
+#ifndef PTRT_DEFAULT_DEVICE
+#define PTRT_DEFAULT_DEVICE 0
+#endif
 class Scene {
   public:
     struct PerformanceSettings { // scene.cuh:189-199
@@ -216,9 +235,11 @@ class Scene {
     // Scene(w,h) of the reference; the extra arguments select a band of rows and a
     // device for tile-parallel rendering and default to "whole frame,
     // device 0".
-    Scene(int w, int h, int tile_y0 = 0, int tile_rows = 0, int device = 0)
+    Scene(int w, int h, int tile_y0 = 0, int tile_rows = 0, int device = PTRT_DEFAULT_DEVICE)
         : width(w), height(h), camera(static_cast<float>(w) / h, 2.0f, 1.0f) {
         tileRows = tile_rows > 0 ? tile_rows : h;
+        tileY0 = tile_y0;
+        device_ = device;
         render_width = w;
         render_height = h;
         if (device < 0)
@@ -230,13 +251,19 @@ class Scene {
             ctx = nullptr;
             throw std::runtime_error(msg);
         }
-        check(ptrt_reset_rng(ctx, PTRT_DEFAULT_SEED), "Failed to init rand states"); // scene.cuh:433-456
-        if (tileRows == h && tile_y0 == 0) {
-            // `denoiser_ = new Denoiser(settings)` (scene.cuh:1984-1993): exists from construction,
-            // used while perfSettings.enableDenoiser; band contexts cannot denoise (filters cross bands)
-            fullFrame = true;
-            check(ptrt_denoiser_enable(ctx, nullptr), "Failed to create denoiser");
-            denoiserAllocated = true;
+        try { // a constructor that throws never runs ~Scene: the context must not outlive it
+            check(ptrt_reset_rng(ctx, PTRT_DEFAULT_SEED), "Failed to init rand states"); // scene.cuh:433-456
+            if (tileRows == h && tile_y0 == 0) {
+                // `denoiser_ = new Denoiser(settings)` (scene.cuh:1984-1993): exists from construction,
+                // used while perfSettings.enableDenoiser; band contexts cannot denoise (filters cross bands)
+                fullFrame = true;
+                check(ptrt_denoiser_enable(ctx, nullptr), "Failed to create denoiser");
+                denoiserAllocated = true;
+            }
+        } catch (...) {
+            ptrt_destroy(ctx);
+            ctx = nullptr;
+            throw;
         }
         prev_view_proj = camera.get_view_proj();
     }
@@ -621,10 +648,59 @@ class Scene {
     }
     int getRenderWidth() const { return render_width; }
     int getRenderHeight() const { return render_height; }
-    // not in the reference (its samplesPerPixel is only reachable through the
-    // "ultra" preset); needed to express the 4-spp benchmark configurations
-    void setSamplesPerPixel(int spp) { perfSettings.samplesPerPixel = spp < 1 ? 1 : spp; }
+    // scene.cuh:1248-1255: stored, accumulation reset -- and IGNORED by render_to_device, which takes its sample
+    // count and depth from perfSettings (scene.cuh:86-87, 1044-1045).  Kept that way so a caller of the
+    // reference renders the same frame here.
+    void setSamplesPerPixel(int spp) { samples_per_pixel_ = spp; resetAccumulation(); }
+    void setMaxDepth(int depth) { max_depth_ = depth; resetAccumulation(); }
+    int getSamplesPerPixel() const { return samples_per_pixel_; } // scene.cuh:1720
+    // NOT in the reference, whose perfSettings.samplesPerPixel is reachable only through the "ultra" preset
+    // (scene.cuh:1839): the sample count render_to_device uses; needed to express the 4-spp configurations.
+    void setPerfSamplesPerPixel(int spp) { perfSettings.samplesPerPixel = spp < 1 ? 1 : spp; }
     const PerformanceSettings &getPerformanceSettings() const { return perfSettings; }
+
+    // ---- debug visualisation (scene.cuh:1564-1684, app_utils.cuh:304-368): out of scope -- the
+    // switches and ray lists are kept so call sites compile and behave, no helper meshes are generated
+    void setWireframeMode(bool e) { wireframe_mode = e; }
+    bool isWireframeMode() const { return wireframe_mode; }
+    void toggleWireframeMode() { wireframe_mode = !wireframe_mode; }
+    void setShowFrustum(bool show) { show_frustum = show; }
+    void toggleFrustum() { show_frustum = !show_frustum; }
+    void setShowRays(bool show) { show_rays = show; }
+    void setRayLength(float length) { ray_length = length; }
+    void addDebugRay(const vec3 &origin, const vec3 &direction) { debug_rays.push_back({origin, direction, -1.0f}); }
+    void addDebugRayWithLength(const vec3 &origin, const vec3 &direction, float length) {
+        debug_rays.push_back({origin, direction.normalized(), length});
+    }
+    void clearDebugRays() { debug_rays.clear(); }
+    size_t getDebugRayCount() const { return debug_rays.size(); }
+    void clearVisualizationMeshes() {}
+    void updateVisualizationMeshes() {
+        if ((show_frustum || (show_rays && !debug_rays.empty())) && !warnedViz) {
+            std::cerr << "NOTE: frustum / ray visualisation meshes are not generated by this back end\n";
+            warnedViz = true;
+        }
+        show_frustum = false;
+    }
+    void generatePrimaryRayVisualization(Camera cam, int numRays = 10) {
+        clearDebugRays();
+        const int gridSize = (int)sqrt((double)numRays);
+        for (int y = 0; y < gridSize; ++y)
+            for (int x = 0; x < gridSize; ++x) {
+                vec3 o, d;
+                cam.get_ray((x + 0.5f) / gridSize, (y + 0.5f) / gridSize, o, d);
+                addDebugRay(o, d);
+            }
+        std::cout << "generated primary rays" << '\n';
+    }
+    // the wireframe debug kernel is out of scope: says so once and shows the path-traced frame instead
+    void render_to_device_wireframe(unsigned char *device_pixels, float /*wireframeThickness*/) {
+        if (!warnedViz) {
+            std::cerr << "NOTE: wireframe rendering is not part of this back end; rendering the path-traced frame\n";
+            warnedViz = true;
+        }
+        render_to_device(device_pixels);
+    }
 
     // ---- upload + render -------------------------------------------------------------
     void uploadToGPU() { // scene.cuh:1643-1657
@@ -705,6 +781,9 @@ class Scene {
 
     int getWidth() const { return width; }
     int getHeight() const { return height; }
+    int getTileRows() const { return tileRows; } // rows this context renders (== height unless it is a band)
+    int getTileY0() const { return tileY0; }
+    int getDevice() const { return device_; }
     size_t getPixelBufferSize() const { return (size_t)width * height * 3; }
     int getFrameCount() const { return frame_count_; }
     // DEVICE pointers, as in the reference (scene.cuh:1722-1725)
@@ -728,8 +807,16 @@ class Scene {
     }
 
   private:
-    int width, height, tileRows = 0;
+    int width, height, tileRows = 0, tileY0 = 0, device_ = 0;
+    int samples_per_pixel_ = 16, max_depth_ = 8; // scene.cuh:86-87: stored, ignored by render_to_device
     int frame_count_ = 0;
+    struct DebugRay {
+        vec3 origin, direction;
+        float length; // < 0: the scene's ray_length
+    };
+    std::vector<DebugRay> debug_rays;
+    bool wireframe_mode = false, show_frustum = false, show_rays = false, warnedViz = false;
+    float ray_length = 5.0f;
     int bvhLeafTarget_ = 12, bvhLeafTol_ = 5; // scene.cuh:90-91
     std::vector<std::unique_ptr<Mesh>> meshes;
     std::vector<Material> mesh_materials;

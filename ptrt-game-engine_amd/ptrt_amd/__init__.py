@@ -174,6 +174,10 @@ _sig("ptrt_set_env_map", C.c_int, _vp, _fp, C.c_int, C.c_int)
 _sig("hs_set_bvh_leaf_target", None, _vp, C.c_int, C.c_int)
 _sig("hs_set_max_bounce_depth", None, _vp, C.c_int)
 _sig("hs_set_samples_per_pixel", None, _vp, C.c_int)
+_sig("hs_set_perf_samples_per_pixel", None, _vp, C.c_int)
+_sig("hs_set_max_depth", None, _vp, C.c_int)
+_sig("hs_get_samples_per_pixel", C.c_int, _vp)
+_sig("hs_serialize_scene", C.c_size_t, _vp, _vp, C.c_size_t)
 _sig("hs_set_denoiser_enabled", C.c_int, _vp, C.c_int)
 _sig("hs_set_bloom_enabled", None, _vp, C.c_int)
 _sig("hs_set_performance_preset", C.c_int, _vp, C.c_char_p)
@@ -215,6 +219,11 @@ _sig("ptrt_present_map", C.c_int, _vp, C.c_int, C.POINTER(_vp))
 _sig("ptrt_present_unmap", C.c_int, _vp, C.c_int)
 _sig("ptrt_present_acquire", C.c_int, _vp, C.c_int, C.POINTER(_vp))
 _sig("ptrt_present_destroy", C.c_int, _vp)
+_sig("ptrt_ring_create", C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(_vp))
+_sig("ptrt_ring_map", C.c_int, _vp, C.c_int, C.POINTER(_vp))
+_sig("ptrt_ring_unmap", C.c_int, _vp, C.c_int)
+_sig("ptrt_ring_acquire", C.c_int, _vp, C.c_int, C.POINTER(_vp))
+_sig("ptrt_ring_destroy", None, _vp)
 _sig("hs_flatten", C.POINTER(SceneDesc), _vp)
 
 
@@ -366,7 +375,12 @@ class Scene:
     # settings
     def setBVHLeafTarget(self, target, tol=5): lib.hs_set_bvh_leaf_target(self._h, target, tol)
     def setMaxBounceDepth(self, d): lib.hs_set_max_bounce_depth(self._h, d)
+    # Scene::setSamplesPerPixel / setMaxDepth (scene.cuh:1248-1255): stored and IGNORED by render_to_device, as in
+    # the reference; the sample count a frame uses is perfSettings.samplesPerPixel -> setPerfSamplesPerPixel
     def setSamplesPerPixel(self, n): lib.hs_set_samples_per_pixel(self._h, n)
+    def setMaxDepth(self, d): lib.hs_set_max_depth(self._h, d)
+    def getSamplesPerPixel(self): return lib.hs_get_samples_per_pixel(self._h)
+    def setPerfSamplesPerPixel(self, n): lib.hs_set_perf_samples_per_pixel(self._h, n)
     def setDenoiserEnabled(self, e): self._chk(lib.hs_set_denoiser_enabled(self._h, int(e)))
     def setBloomEnabled(self, e): lib.hs_set_bloom_enabled(self._h, int(e))
     def setPerformancePreset(self, name): self._chk(lib.hs_set_performance_preset(self._h, name.encode()))
@@ -528,6 +542,15 @@ class Scene:
     def saveAsPPM(self, path, pixels):
         a = np.ascontiguousarray(pixels, dtype=np.uint8)
         self._chk(lib.hs_save_ppm(self._h, path.encode(), a.ctypes.data_as(_vp)))
+
+    def serialize(self):
+        """Canonical byte stream of the flattened scene (host/ptrt/serialize.hpp)."""
+        n = lib.hs_serialize_scene(self._h, None, 0)
+        if not n:
+            raise PtrtError(lib.hs_last_error().decode())
+        buf = (C.c_ubyte * n)()
+        lib.hs_serialize_scene(self._h, buf, n)
+        return bytes(buf)
 
     def flatten(self):
         """Pointer to the flattened `ptrt_scene_desc` (host arrays owned by the C++ Scene)."""

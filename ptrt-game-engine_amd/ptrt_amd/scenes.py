@@ -60,6 +60,85 @@ def cornell(scene, quads=False):
     return scene
 
 
+def _f0(ior):
+    f = np.float32((np.float32(ior) - np.float32(1.0)) / (np.float32(ior) + np.float32(1.0)))
+    return float(f * f)  # iorToF0 (material_lib.cuh:142-145) in fp32
+
+
+class Materials:
+    """The application's material library (src/pathtracer/app_utils.cuh:60-191), parameter for parameter, through the
+    same constructor + field assignments.  tests/test_refapp_scenes.py holds the scenes built from it to the scenes
+    the reference's own buildSceneById builds over the C++ mirror."""
+    Silver = staticmethod(lambda: Material((0.97, 0.96, 0.91), 0.05, 1.0))
+    BrushedAluminum = staticmethod(lambda: Material((0.91, 0.92, 0.92), 0.3, 1.0))
+    Gold = staticmethod(lambda: Material((1.00, 0.78, 0.34), 0.1, 1.0))
+    Copper = staticmethod(lambda: Material((0.95, 0.64, 0.54), 0.2, 1.0))
+    Titanium = staticmethod(lambda: Material((0.542, 0.497, 0.449), 0.15, 1.0))
+    Glass = staticmethod(lambda: Material((1.0, 1.0, 1.0), 0.0, transmission=1.0, ior=1.5, specular=(_f0(1.5),) * 3))
+    FrostedGlass = staticmethod(lambda: Materials.Glass().set("roughness", 0.2))
+    Water = staticmethod(lambda: Materials.Glass().set("ior", 1.33))
+    Diamond = staticmethod(lambda: Materials.Glass().set("ior", 2.417).set("specular", (_f0(2.417),) * 3))
+    SoapBubble = staticmethod(lambda: Material((1.0, 1.0, 1.0), 0.0, transmission=0.95, ior=1.01, iridescence=1.0,
+                                               iridescenceThickness=400.0))
+    OilSlick = staticmethod(lambda: Material((0.1, 0.1, 0.1), 0.4, 0.8, iridescence=1.0, iridescenceThickness=600.0))
+    VelvetRed = staticmethod(lambda: Material((0.4, 0.01, 0.05), 0.8, sheen=1.0, sheenTint=(1.0, 0.5, 0.5)))
+    SatinBlue = staticmethod(lambda: Material((0.1, 0.1, 0.6), 0.3, sheen=0.8, anisotropy=0.6))
+    # metallic is assigned AFTER construction, so specular stays 0.04 (app_utils.cuh:133-139)
+    CarPaintMidnight = staticmethod(lambda: Material((0.02, 0.02, 0.15), 0.5, clearcoat=1.0,
+                                                     clearcoatRoughness=0.01).set("metallic", 0.4))
+    LacqueredWood = staticmethod(lambda: Material((0.2, 0.1, 0.02), 0.6, clearcoat=1.0, clearcoatRoughness=0.05))
+    PlasticRed = staticmethod(lambda: Material((0.8, 0.1, 0.1), 0.3))
+    RubberBlack = staticmethod(lambda: Material((0.05, 0.05, 0.05), 0.8))
+    Wax = staticmethod(lambda: Material((0.9, 0.8, 0.5), 0.3, transmission=0.2))
+    Jade = staticmethod(lambda: Material((0.1, 0.6, 0.3), 0.4, subsurfaceRadius=1.0, subsurfaceColor=(0.1, 0.8, 0.4)))
+    MarbleCarrara = staticmethod(lambda: Material((0.95, 0.95, 0.95), 0.1, 0.5))
+
+    @staticmethod
+    def GlowingNeon(color):
+        e = np.asarray(color, dtype=np.float32) * np.float32(10.0)
+        return Material((0.0, 0.0, 0.0)).set("emission", e)
+
+
+def lit_test(scene):
+    """Scenes::createLitTestScene (app_utils.cuh:196-206), scene id 0 and the fallback of buildSceneById."""
+    scene.addPlaneXZ(-1.0, 50.0, Material((0.8, 0.8, 0.8), 0.5))
+    cube = scene.addCube(Materials.Silver())
+    scene.moveTo(cube, (0, 0.5, 3))
+    scene.addSpotLight((-3, 5, 2), (1, -1, 1), (1.0, 1.0, 1.0), 5.0)
+    scene.addPointLight((2, 3, 1), (0.8, 0.8, 1.0), 2.0)
+    scene.setCamera((0, 1.5, -2), (0, 0.5, 3), (0, 1, 0), 60.0)
+    return scene
+
+
+def material_matrix(scene):
+    """buildSceneById case 10, "Material Matrix (Cubes)" (app_utils.cuh:729-795): a floor and a 4 x 4 grid of cubes,
+    one per material class of the path (metals, clearcoat, plastics, glass, thin film, sheen, subsurface, emitter)."""
+    scene.addPlaneXZ(-1.0, 50.0, Material((0.2, 0.2, 0.2), 0.8))
+    rows = cols = 4
+    spacing = np.float32(2.0)
+    start_x = -(np.float32(cols - 1) * spacing) / np.float32(2.0)
+    start_z = -(np.float32(rows - 1) * spacing) / np.float32(2.0) - np.float32(5.0)
+    M = Materials
+    palette = [M.Silver(), M.Gold(), M.Copper(), M.Titanium(), M.CarPaintMidnight(), M.PlasticRed(), M.RubberBlack(),
+               M.LacqueredWood(), M.Glass(), M.FrostedGlass(), M.SoapBubble(), M.OilSlick(), M.VelvetRed(), M.SatinBlue(),
+               M.Jade(), M.GlowingNeon((0.2, 1.0, 0.2))]
+    for r in range(rows):
+        for c in range(cols):
+            cube = scene.addCube(palette[r * cols + c])
+            x = float(start_x + np.float32(c) * spacing)
+            z = float(start_z + np.float32(r) * spacing)
+            scene.scale(cube, 0.7)
+            scene.moveTo(cube, (x, 0.0, z))
+            scene.moveTo(cube, (x, float(np.float32(-1.0) + np.float32(0.7)), z))
+            scene.rotateSelfEulerXYZ(cube, (0, 0.7, 0))
+    scene.addSpotLight((0, 8, -5), (0, -1, 0), (1.0, 1.0, 1.0), 10.0, 0.1, 0.5, 2.0, 0.1)
+    scene.addPointLight((-5, 2, -2), (1.0, 0.8, 0.8), 2.0, 10.0, 0.2)
+    scene.addPointLight((5, 2, -2), (0.8, 0.8, 1.0), 2.0, 10.0, 0.2)
+    scene.setCamera((0, 6, 4), (0, 0, -5), (0, 1, 0), 50.0)
+    scene.setSkyGradient((0.1, 0.1, 0.1), (0.02, 0.02, 0.02))
+    return scene
+
+
 def _showcase_materials():
     m = []
     m.append(Material((0.95, 0.64, 0.54), 0.2, 1.0))                                   # Copper

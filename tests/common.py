@@ -13,7 +13,7 @@ def render_both(P, O, scene, blue_noise, spp, depth, frames=1, threads=8, count=
     """Renders `frames` consecutive frames on the GPU and in the oracle from the same initial
     generator states.  Returns (gpu, cpu): lists of dicts of buffers per frame."""
     W, rows, y0 = scene.width, scene.tile_rows, scene.tile_y0
-    scene.setSamplesPerPixel(spp)
+    scene.setPerfSamplesPerPixel(spp)
     scene.setMaxBounceDepth(depth)
     scene.setDenoiserEnabled(False)
     scene.setBloomEnabled(False)

@@ -82,7 +82,7 @@ def test_equals_megakernel_at_scale(P, blue_noise):
     for wf in (0, 1):
         s = P.Scene(640, 360)
         P.scenes.showcase(s)
-        s.setSamplesPerPixel(4)
+        s.setPerfSamplesPerPixel(4)
         s.setMaxBounceDepth(4)
         s.setDenoiserEnabled(False)
         s.setBloomEnabled(False)

@@ -101,7 +101,7 @@ def test_radix_sort_at_scale_and_rebuild_from_device(P, O, blue_noise):
     hip.hipFree.argtypes = [C.c_void_p]
     s = P.Scene(128, 72)
     w, ship = P.scenes.fluid(s, cells=256, t=0.0, ship_segments=16)
-    s.setSamplesPerPixel(1)
+    s.setPerfSamplesPerPixel(1)
     s.setMaxBounceDepth(3)
     s.setDenoiserEnabled(False)
     s.setBloomEnabled(False)

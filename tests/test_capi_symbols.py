@@ -27,7 +27,7 @@ def test_struct_layouts_match_reference_sizes(P):
     assert ctypes.sizeof(P.Vec3) == 12 and ctypes.sizeof(P.BvhNode) == 40 and ctypes.sizeof(P.Tri) == 12
     assert ctypes.sizeof(P.Light) == 60 and ctypes.sizeof(P.Hit) == 64
     assert P.Light.position.offset == 4 and P.Light.color.offset == 28 and P.Light.radius.offset == 56
-    assert P.lib.ptrt_abi_version() == 3
+    assert P.lib.ptrt_abi_version() == 4
 
 
 def test_no_cpu_fallback(P):
@@ -52,3 +52,44 @@ def test_bad_arguments_are_rejected(P):
     assert P.lib.ptrt_create(0, 64, 0, 0, 0, ctypes.byref(ctx)) == -1
     assert P.lib.ptrt_create(64, 64, 60, 10, 0, ctypes.byref(ctx)) == -1
     assert P.lib.ptrt_render(None, 0, 1, 1, None, 0) == -1
+
+
+def test_stale_and_foreign_handles_are_refused_without_touching_them(P):
+    """A destroyed (or never created) handle must be answered with PTRT_E_INVALID and its memory left alone
+    (fail() used to write the message into the freed context)."""
+    buf = ctypes.create_string_buffer(4096)  # stands in for a freed ptrt_ctx: never in the live set
+    stale = ctypes.cast(buf, ctypes.c_void_p)
+    before = bytes(buf.raw)
+    assert P.lib.ptrt_render(stale, 0, 1, 1, None, 0) == -1
+    assert P.lib.ptrt_reset_rng(stale, 1) == -1
+    assert P.lib.ptrt_refit(stale) == -1
+    assert P.lib.ptrt_sync(stale) == -1
+    assert P.lib.ptrt_set_option(stale, b"count_rays", 1) == -1
+    assert bytes(buf.raw) == before, "an entry point wrote into a handle that is not a live context"
+    assert b"ptrt_set_option" in P.lib.ptrt_last_error(stale)  # falls back to the thread's last message
+    P.lib.ptrt_destroy(stale)  # tolerated, not freed
+    assert bytes(buf.raw) == before
+    # rings: same rule
+    assert P.lib.ptrt_ring_map(stale, 0, ctypes.byref(ctypes.c_void_p())) == -1
+    assert P.lib.ptrt_ring_unmap(stale, 0) == -1
+    P.lib.ptrt_ring_destroy(stale)
+    assert bytes(buf.raw) == before
+    ring = ctypes.c_void_p()
+    assert P.lib.ptrt_ring_create(0, 0, 2, ctypes.byref(ring)) == -1 and not ring.value
+
+
+def test_reference_setters_do_not_change_what_a_frame_uses(P):
+    """Scene::setSamplesPerPixel / setMaxDepth are stored and ignored by render_to_device (scene.cuh:86-87,
+    1248-1255); the frame's sample count and depth are perfSettings' (scene.cuh:1044-1045)."""
+    s = P.Scene(64, 64, device=P.HOST_ONLY)
+    assert s.getSamplesPerPixel() == 16 and s.settings()["spp"] == 1 and s.settings()["depth"] == 4
+    s.setFrameCount(5)
+    s.setSamplesPerPixel(64)
+    s.setMaxDepth(2)
+    assert s.getSamplesPerPixel() == 64 and s.getFrameCount() == 0  # resetAccumulation
+    assert s.settings()["spp"] == 1 and s.settings()["depth"] == 4
+    s.setPerfSamplesPerPixel(4)
+    assert s.settings()["spp"] == 4 and s.getSamplesPerPixel() == 64
+    s.setPerformancePreset("ultra")  # scene.cuh:1839-1840
+    assert s.settings()["spp"] == 128 and s.settings()["depth"] == 32
+    s.close()

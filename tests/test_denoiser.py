@@ -91,7 +91,7 @@ def test_motion_vectors_follow_the_camera(P, O, blue_noise):
 def test_gpu_denoiser_bit_exact(P, O, blue_noise, size, spp):
     W, H = size
     s = cornell(P, W, H)
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(4)
     s.setDenoiserEnabled(True)
     s.setBloomEnabled(False)
@@ -139,7 +139,7 @@ def test_gpu_thin_lens_camera_motion_vectors_and_frames(P, O, blue_noise):
     W, H, spp = 80, 56, 2
     s = cornell(P, W, H)
     s.setCamera((0, 0, 5), (0, 0, -5), (0, 1, 0), 40.0, 0.2, 10.0)
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(3)
     s.setDenoiserEnabled(True)
     s.setBloomEnabled(False)

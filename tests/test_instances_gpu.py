@@ -33,7 +33,7 @@ def test_moving_instances_take_the_fast_path_and_match_the_oracle(P, O, blue_noi
     s.setInstanceScale(cube, (1.2, 0.7, 1.0))
     ball = s.addSphere(8, P.Material((0.9, 0.9, 0.2), 0.05, 1.0))
     s.setPosition(ball, (-2.0, 1.5, -4.0))
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     s.setDenoiserEnabled(False)
     s.setBloomEnabled(False)

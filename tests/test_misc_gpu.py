@@ -39,7 +39,7 @@ def test_gpu_reproduces_committed_goldens(P, name):
     g = np.load(os.path.join(GOLD, f"oracle_{name}.npz"))
     s = P.Scene(w, h)
     P.scenes.cornell(s) if scene == "cornell" else P.scenes.showcase(s, segments=12)
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     s.setDenoiserEnabled(False)
     s.setBloomEnabled(False)
@@ -88,7 +88,7 @@ def test_full_size_properties(P):
     """1920x1080, 4 spp, 4 bounces (BASELINE configs[1]): properties that need no oracle run."""
     s = P.Scene(1920, 1080)
     P.scenes.cornell(s)
-    s.setSamplesPerPixel(4)
+    s.setPerfSamplesPerPixel(4)
     s.setMaxBounceDepth(4)
     s.setDenoiserEnabled(False)
     s.setBloomEnabled(False)
@@ -119,7 +119,7 @@ def test_full_size_properties(P):
     parts = []
     for t in (top, bot):
         P.scenes.cornell(t)
-        t.setSamplesPerPixel(4)
+        t.setPerfSamplesPerPixel(4)
         t.setMaxBounceDepth(4)
         t.initBlueNoise()
         t.uploadToGPU()
@@ -132,7 +132,7 @@ def test_full_size_properties(P):
 def _frames(P, build, opts, W=1920, H=1080, spp=4, depth=4, n_frames=2):
     s = P.Scene(W, H)
     build(s)
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     s.setDenoiserEnabled(False)
     s.setBloomEnabled(False)

@@ -71,7 +71,7 @@ def test_render_size_follows_resolution_scale(P):
 # ------------------------------------------------------------------------------------------ GPU
 def setup(P, W, H, spp=2, depth=4, denoise=False, bloom=False, scale=1.0):
     s = cornell(P, W, H)
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     s.setDenoiserEnabled(denoise)
     s.setBloomEnabled(bloom)

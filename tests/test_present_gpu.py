@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 def make(P, W=96, H=64):
     s = P.Scene(W, H)
     P.scenes.cornell(s)
-    s.setSamplesPerPixel(1)
+    s.setPerfSamplesPerPixel(1)
     s.setMaxBounceDepth(3)
     s.setDenoiserEnabled(False)
     s.setBloomEnabled(False)

@@ -102,7 +102,7 @@ def test_refit_and_rebuild_behind_a_real_tlas(P, O, blue_noise, rebuild):
     s = P.Scene(W, H)
     _many_meshes(P, s, n=24)
     blob = s.addSphere(16, P.Material((0.8, 0.4, 0.1), 0.3))
-    s.setSamplesPerPixel(spp)
+    s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     s.setDenoiserEnabled(False)
     s.setBloomEnabled(False)

@@ -59,7 +59,7 @@ def test_bands_plus_presenting_context_equal_the_full_frame_presets(P, blue_nois
     def make(**kw):
         s = P.Scene(Wg, Hg, **kw)
         P.scenes.cornell(s)
-        s.setSamplesPerPixel(spp)
+        s.setPerfSamplesPerPixel(spp)
         s.setMaxBounceDepth(depth)
         s.initBlueNoise()
         return s

@@ -14,7 +14,7 @@ s = P.Scene(1920, 1080)
 P.scenes.showcase(s)
 ball = s.addSphere(71, P.Material((0.9, 0.2, 0.2), 0.3))
 s.setPosition(ball, (0.0, 2.0, -5.0))
-s.setSamplesPerPixel(4)
+s.setPerfSamplesPerPixel(4)
 s.setMaxBounceDepth(4)
 s.setDenoiserEnabled(False)
 s.setBloomEnabled(False)

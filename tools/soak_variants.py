@@ -11,7 +11,7 @@ import ptrt_amd as P
 from test_parity_gpu import _many_meshes
 def frames(build, opts, n, spp):
     s = P.Scene(1920, 1080); build(s)
-    s.setSamplesPerPixel(spp); s.setMaxBounceDepth(4); s.setDenoiserEnabled(False); s.setBloomEnabled(False)
+    s.setPerfSamplesPerPixel(spp); s.setMaxBounceDepth(4); s.setDenoiserEnabled(False); s.setBloomEnabled(False)
     s.initBlueNoise(); s.uploadToGPU(); s.set_option("count_rays", 1)
     for k, v in opts.items(): s.set_option(k, v)
     out = []

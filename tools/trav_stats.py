@@ -17,7 +17,7 @@ from bench import build_scene  # noqa: E402
 scene = sys.argv[1] if len(sys.argv) > 1 else "showcase"
 W, H, spp = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (1920, 1080, 4)
 s = build_scene(P, scene, W, H, 0, 0, 0)
-s.setSamplesPerPixel(spp)
+s.setPerfSamplesPerPixel(spp)
 s.setMaxBounceDepth(4)
 s.initBlueNoise()
 s.uploadToGPU()

@@ -59,6 +59,7 @@ struct KParams {
     const float4 *tlas_nodes; // child-pair nodes over meshes
     const int2 *tlas_leaves;  // {first index into tlas_mesh_ids, count}
     const int *tlas_mesh_ids;
+    const float4 *tlas_heads; // PMODE 3: per TLAS index (leaf order) 5 float4 of the mesh record: {bmin, root ref}, {bmax, flags}, inverse rows
     const float4 *materials; // 6 float4 per mesh
     const float4 *lights;    // 4 float4 per light
     const float2 *blue_noise; // 64*64
@@ -77,6 +78,7 @@ struct KParams {
     int leaf_min;       // PMODE 2: lanes waiting at a leaf that end the node loop (64 = all of them)
     int leaf_pairs;     // PMODE 2: leaf phase as compacted (lane, triangle) pairs
     int fetch_min;      // PMODE 2: idle lanes before the wave refills from the pair list (0 = static 64-pair batches)
+    int pair_cap;       // PMODE 4: entries the LDS pair list holds (a multiple of 64, >= 64 * pair_meshes + 64)
     // frame
     Camera cam;
     f3 sky_top, sky_bottom;
@@ -97,6 +99,7 @@ struct KParams {
 };
 
 constexpr int MESH_REC_F4 = 12;
+constexpr int TLAS_HEAD_F4 = 5; // head + the three rows of the inverse matrix: what the root-box test of an instance needs
 constexpr float T_FAR = 1e30f;
 
 PT_DEV f3 tlas_bmin(const KParams &K) {
@@ -116,9 +119,12 @@ PT_DEV RayO make_ray(f3 o, f3 d) {
     RayO r;
     r.o = o;
     r.d = d;
-    r.inv.x = (__builtin_fabsf(d.x) > 1e-8f) ? (1.0f / d.x) : ((d.x >= 0) ? 1e30f : -1e30f);
-    r.inv.y = (__builtin_fabsf(d.y) > 1e-8f) ? (1.0f / d.y) : ((d.y >= 0) ? 1e30f : -1e30f);
-    r.inv.z = (__builtin_fabsf(d.z) > 1e-8f) ? (1.0f / d.z) : ((d.z >= 0) ? 1e30f : -1e30f);
+    // 1/d through rcp_ieee (bit-identical to the division for every input, tests/test_misc_gpu.py): a ray is set up
+    // per (ray, mesh) pair and per instance root test, and three compiler divisions were a fifth of that
+    const bool bx = __builtin_fabsf(d.x) > 1e-8f, by = __builtin_fabsf(d.y) > 1e-8f, bz = __builtin_fabsf(d.z) > 1e-8f;
+    r.inv.x = bx ? rcp_ieee(bx ? d.x : 1.0f) : ((d.x >= 0) ? 1e30f : -1e30f);
+    r.inv.y = by ? rcp_ieee(by ? d.y : 1.0f) : ((d.y >= 0) ? 1e30f : -1e30f);
+    r.inv.z = bz ? rcp_ieee(bz ? d.z : 1.0f) : ((d.z >= 0) ? 1e30f : -1e30f);
     r.sx = r.inv.x < 0;
     r.sy = r.inv.y < 0;
     r.sz = r.inv.z < 0;
@@ -354,6 +360,12 @@ PT_DEV MeshHead load_mesh_head(const KParams &K, int m) {
     return h;
 }
 // local-space ray of a transformed instance (transformRayToLocal, intersection.cuh:284-297)
+PT_DEV RayO local_ray_rows(const float4 i0, const float4 i1, const float4 i2, const RayO &w, float &dirScale) {
+    const f3 lo = xform_point(i0, i1, i2, w.o);
+    const f3 ld = xform_dir(i0, i1, i2, w.d);
+    dirScale = length(ld);
+    return make_ray(lo, normalize(ld));
+}
 PT_DEV RayO local_ray(const KParams &K, int m, const RayO &w, float &dirScale) {
     const float4 i0 = K.mesh_recs[m * MESH_REC_F4 + 2], i1 = K.mesh_recs[m * MESH_REC_F4 + 3],
                  i2 = K.mesh_recs[m * MESH_REC_F4 + 4];
@@ -666,6 +678,18 @@ __global__ __launch_bounds__(256) void xorwow_init_kernel(uint32_t *rng, int wid
     rng[3 * npix + i] = v[2];
     rng[4 * npix + i] = v[3];
     rng[5 * npix + i] = v[4];
+}
+
+// PMODE 3: the heads of the mesh records in TLAS-leaf order, refreshed before a frame (root boxes move under a GPU
+// refit, the shadow-skip flag with the materials): a lane's leaf is then ONE level of loads away instead of two
+__global__ void gather_tlas_heads_kernel(const float4 *__restrict__ mesh_recs, const int *__restrict__ ids, int n,
+                                         float4 *__restrict__ heads) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    const int m = ids[j];
+    for (int k = 0; k < TLAS_HEAD_F4; ++k)
+        heads[TLAS_HEAD_F4 * j + k] = mesh_recs[m * MESH_REC_F4 + k];
 }
 
 // canonical {d,v0..v4}-per-pixel order <-> the private planar layout

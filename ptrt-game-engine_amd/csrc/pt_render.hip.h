@@ -41,6 +41,7 @@ namespace pt {
 struct PairLds {
     float4 *tris;             // pair_tri_slots * 3
     int4 *meshtab;            // per mesh order: {first slot, count, flags, mesh id}
+    float4 *meshbox;          // per mesh order: {bmin, root ref}, {bmax, flags}: the mesh record's head, staged once
     uint32_t *pairs;          // 64 * pair_meshes
     float *ray;               // 6 planes of 64
     unsigned long long *best; // 64
@@ -53,20 +54,29 @@ struct PairLds {
     unsigned char *owner;     // 64 * 17 rounded up: lane of each test
 };
 constexpr int LEAF_PAIR_BYTES = 512 + 1152;
+// PMODE 3: TLAS leaves a ray may have in one fill of the pair list (a power of two <= 4) and the pairs that end a fill
+#ifndef PT_TLAS_SLOTS
+#define PT_TLAS_SLOTS 1
+#endif
+constexpr int TLAS_SLOTS = PT_TLAS_SLOTS;
+constexpr int TLAS_FILL_TARGET = 64;
 constexpr int PAIR_PAD = 2; // float4 of padding in front of each mesh's packets in LDS (bank spreading)
 PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_entries = 0, int tlas_leaf = 0,
-                              int tlas_depth = 0) {
+                              int tlas_depth = 0, int pair_cap = 0) {
     PairLds l;
     char *p = (char *)base;
     l.tris = (float4 *)p;
     p += tri_slots ? ((size_t)tri_slots * 48 + (size_t)meshes * PAIR_PAD * 16) : 0;
     l.meshtab = (int4 *)p;
     p += (size_t)meshes * 16;
+    l.meshbox = (float4 *)p;
+    p += (size_t)meshes * 32;
     l.best = (unsigned long long *)p;
-    p += 512;
+    p += tlas_leaf ? 512 * TLAS_SLOTS : 512; // (PMODE 3: one minimum per ray and leaf slot)
     l.pairs = (uint32_t *)p;
     // PMODE 2 and 3 (the modes with a stack) pack them in 16 bits; PMODE 3 holds one TLAS leaf per ray at a time
-    p += tlas_leaf ? (size_t)tlas_leaf * 128 : (size_t)meshes * (stack_entries ? 128 : 256);
+    // (PMODE 4 keeps the pairs of both ray kinds in one list of pair_cap 16-bit entries)
+    p += pair_cap ? (size_t)pair_cap * 2 : tlas_leaf ? ((size_t)tlas_leaf * 64 + TLAS_FILL_TARGET) * 2 : (size_t)meshes * (stack_entries ? 128 : 256);
     l.ray = (float *)p;
     p += stack_entries ? 0 : 6 * 256; // (PMODE 1 only)
     l.occ = (uint32_t *)p;
@@ -76,7 +86,7 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     l.tstack = (uint2 *)p;
     p += (size_t)tlas_depth * 512;
     l.leafx = (int *)p;
-    p += tlas_leaf ? 256 : 0;
+    p += tlas_leaf ? 256 * TLAS_SLOTS : 0;
     l.lkey = (unsigned long long *)p;
     p += 512;
     l.owner = (unsigned char *)p;
@@ -108,12 +118,29 @@ struct TravStats {
 };
 #define TS_WAVE(i) ts.wave(i, lane)
 #define TS_LANE(i) ts.lanes(i)
+// wave-level cycle accounting (s_memtime), accumulated in scalar registers and flushed once per wave at kernel end
+// (an atomic per interval would be what the kernel spends its time on)
+struct CycleAcc {
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PT_DEV void flush(int lane) {
+        if (lane == 0)
+            for (int i = 0; i < 8; ++i)
+                atomicAdd(&g_trav_stats[8 + i], c[i]);
+    }
+};
+#define TS_NOW() __builtin_readcyclecounter()
+#define TS_ADD(slot, t) (cyc.c[(slot) - 8] += __builtin_readcyclecounter() - (t))
 #else
 struct TravStats {
     PT_DEV void flush(int, int) {}
 };
 #define TS_WAVE(i)
 #define TS_LANE(i)
+struct CycleAcc {
+    PT_DEV void flush(int) {}
+};
+#define TS_NOW() 0ull
+#define TS_ADD(slot, t) (void)(t)
 #endif
 
 PT_DEV void wave_lds_order() { // LDS is in order within a wave; this only pins the compiler
@@ -123,6 +150,17 @@ PT_DEV void wave_lds_order() { // LDS is in order within a wave; this only pins 
 
 PT_DEV int lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// head of the i-th mesh of the (single) TLAS leaf from its LDS copy; root reference and flags made scalar
+PT_DEV MeshHead staged_mesh_head(const PairLds &L, int i) {
+    const float4 a = L.meshbox[2 * i], b = L.meshbox[2 * i + 1];
+    MeshHead h;
+    h.bmin = mk3(a.x, a.y, a.z);
+    h.bmax = mk3(b.x, b.y, b.z);
+    h.root_ref = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));
+    h.flags = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
+    return h;
 }
 
 // step 1: root-box tests + ballot/prefix-sum compaction into the LDS pair list
@@ -143,16 +181,17 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
         L.occ[lane] = 0u;
     else
         L.best[lane] = ~0ull;
-    const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+    // (the mesh heads come out of LDS, staged at kernel start: read from memory here -- mesh id, then its record, one
+    // dependent round trip each -- the loop took ~0.7 us per mesh and ~25 % of a showcase wave's time)
     int base = 0;
-    for (int i = 0; i < lf.y; ++i) {
-        const int m = __builtin_amdgcn_readfirstlane(K.tlas_mesh_ids[lf.x + i]);
-        const MeshHead mh = load_mesh_head(K, m);
+    for (int i = 0; i < K.pair_meshes; ++i) {
+        const MeshHead mh = staged_mesh_head(L, i);
         if (ANY && (mh.flags & 2))
             continue;
         bool hb;
         if (mh.flags & 1) {
             float ds;
+            const int m = __builtin_amdgcn_readfirstlane(L.meshtab[i].w);
             const RayO lr = local_ray(K, m, w, ds);
             hb = alive && slab(mh.bmin, mh.bmax, lr, ANY ? tMax * ds : T_FAR, tE);
         } else {
@@ -186,10 +225,11 @@ PT_DEV void pair_ray(const KParams &K, const PairLds &L, int r, const int4 mt, f
 }
 
 // the same from a world ray already in registers (queue modes: fetched from the owner lane by ds_bpermute)
-PT_DEV void pair_ray_from(const KParams &K, const int4 mt, f3 &o, f3 &d, float &dirScale) {
+// (`GEN`: mt.w is a TLAS index and the rows come from the leaf-order copy; else it is a mesh id)
+template <bool GEN = false> PT_DEV void pair_ray_from(const KParams &K, const int4 mt, f3 &o, f3 &d, float &dirScale) {
     dirScale = 1.0f;
     if (mt.z & 1) {
-        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
+        const float4 *rec = GEN ? (K.tlas_heads + mt.w * TLAS_HEAD_F4) : (K.mesh_recs + mt.w * MESH_REC_F4);
         const f3 lo = xform_point(rec[2], rec[3], rec[4], o);
         const f3 ld = xform_dir(rec[2], rec[3], rec[4], d);
         dirScale = length(ld);
@@ -341,9 +381,11 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
 template <bool GEN> PT_DEV int4 pair_mesh(const KParams &K, const PairLds &L, int r, int order) {
     if (!GEN)
         return L.meshtab[order];
-    const int m = K.tlas_mesh_ids[L.leafx[r] + order];
-    const MeshHead mh = load_mesh_head(K, m);
-    return make_int4(mh.root_ref, 0, mh.flags, m);
+    // (root reference and flags from the leaf-order copy of the heads; the mesh id only matters for an instance's matrices)
+    // (order = leaf slot of this fill | index in that leaf << 2)
+    const int j = L.leafx[(order & (TLAS_SLOTS - 1)) * 64 + r] + (order >> 2);
+    const int root = __float_as_int(K.tlas_heads[TLAS_HEAD_F4 * j].w), flags = __float_as_int(K.tlas_heads[TLAS_HEAD_F4 * j + 1].w);
+    return make_int4(root, 0, flags, j);
 }
 
 // drains the pair queue [0, P): afterwards L.best[r] = min over ray r's pairs of {t bits, order << 24 | slot}
@@ -386,7 +428,7 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
                 r = src;
                 oi = (int)(e >> 6);
                 const int4 mt = pair_mesh<GEN>(K, L, r, oi);
-                pair_ray_from(K, mt, po, pd, dirScale);
+                pair_ray_from<GEN>(K, mt, po, pd, dirScale);
                 pr = make_ray(po, pd);
                 xf = (mt.z & 1) != 0;
                 cur = mt.x;
@@ -518,9 +560,11 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
         if (busy && !active) { // this pair is finished: merge it into its ray
             if (sb >= 0) {
                 const float tw = xf ? tb / dirScale : tb;
+                // (GEN: one minimum per leaf slot of the fill; the tie order is the index within that leaf)
+                const int ko = GEN ? (oi >> 2) : oi, kb = GEN ? (oi & (TLAS_SLOTS - 1)) * 64 + r : r;
                 const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)oi << 24) | (uint32_t)sb;
-                __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)ko << 24) | (uint32_t)sb;
+                __hip_atomic_fetch_min(&L.best[kb], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             busy = false;
         }
@@ -606,7 +650,7 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
                 if (L.occ[r] == 0u) {
                     const int4 mt = pair_mesh<GEN>(K, L, r, (int)(e >> 6));
                     float dirScale;
-                    pair_ray_from(K, mt, po, pd, dirScale);
+                    pair_ray_from<GEN>(K, mt, po, pd, dirScale);
                     pr = make_ray(po, pd);
                     tm = tmaxv[r];
                     if (mt.z & 1)
@@ -792,39 +836,80 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
 // and drains them with run_closest_queue; every lane merges its leaf's minimum with strict `<` and walks on with
 // the updated limit.  So a mesh is traced iff the reference traces it.  Shadow rays do the same with the any-hit
 // walk (bvh_any_hit_tlas, intersection.cuh:481-524) and stop at the first blocked round.
+#ifndef PT_ROOT_CHUNK
+#define PT_ROOT_CHUNK 2
+#endif
+// Root-box tests of every lane's NEXT leaf (`slot`-th leaf of this fill) -> pair entries lane | slot << 6 | index << 8
+// appended at `base`; returns the new length of the list.
 template <bool ANY>
-PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, bool has, int2 lf, const RayO &w, float tMax) {
-    L.leafx[lane] = lf.x;
-    if (!ANY)
-        L.best[lane] = ~0ull;
-    int base = 0;
-    for (int i = 0; i < K.tlas_max_leaf; ++i) {
-        bool hb = false;
-        if (has && i < lf.y) {
-            const int m = K.tlas_mesh_ids[lf.x + i];
-            const MeshHead mh = load_mesh_head(K, m);
-            if (!(ANY && (mh.flags & 2))) {
-                float tE;
-                if (mh.flags & 1) {
-                    float ds;
-                    const RayO lr = local_ray(K, m, w, ds);
-                    hb = slab(mh.bmin, mh.bmax, lr, ANY ? tMax * ds : T_FAR, tE);
-                } else {
-                    hb = slab(mh.bmin, mh.bmax, w, ANY ? tMax : T_FAR, tE);
-                }
-            }
+PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, bool has, int2 lf, const RayO &w, float tMax, int slot,
+                               int base) {
+    // Pass 1, lock-step over the leaf's entries: untransformed meshes are tested (world ray, ~30 VALU), instances are only
+    // noted.  Pass 2: every lane walks ITS instances (ray into the instance's space: two transforms, a normalisation,
+    // three divisions -- ~160 VALU), one per iteration whatever their positions in the leaf.  In one lock-step loop every
+    // iteration paid for both kinds as soon as one lane's entry was an instance: that loop was most of a PMODE 3 frame.
+    uint32_t mask = 0u, inst = 0u;
+    for (int i0 = 0; i0 < K.tlas_max_leaf; i0 += PT_ROOT_CHUNK) {
+        float4 ha[PT_ROOT_CHUNK], hb4[PT_ROOT_CHUNK];
+#pragma unroll
+        for (int k = 0; k < PT_ROOT_CHUNK; ++k) {
+            const bool in = has && (i0 + k) < lf.y;
+            const int j = in ? lf.x + i0 + k : 0;
+            ha[k] = K.tlas_heads[TLAS_HEAD_F4 * j];
+            hb4[k] = K.tlas_heads[TLAS_HEAD_F4 * j + 1];
         }
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hb);
-        if (hb)
-            ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)i << 6));
-        base += __builtin_popcountll(bal);
-        if (!__builtin_amdgcn_ballot_w64(has && i + 1 < lf.y))
+#pragma unroll
+        for (int k = 0; k < PT_ROOT_CHUNK; ++k) {
+            const int flags = __float_as_int(hb4[k].w);
+            const bool in = has && (i0 + k) < lf.y && !(ANY && (flags & 2));
+            float tE;
+            const bool hb = slab(mk3(ha[k].x, ha[k].y, ha[k].z), mk3(hb4[k].x, hb4[k].y, hb4[k].z), w, ANY ? tMax : T_FAR, tE);
+            const bool is_inst = (flags & 1) != 0;
+            mask |= (in && !is_inst && hb) ? (1u << (i0 + k)) : 0u;
+            inst |= (in && is_inst) ? (1u << (i0 + k)) : 0u;
+        }
+        if (!__builtin_amdgcn_ballot_w64(has && i0 + PT_ROOT_CHUNK < lf.y))
             break;
+    }
+    while (__builtin_amdgcn_ballot_w64(inst != 0u)) {
+        if (inst != 0u) {
+            const int i = __builtin_ctz(inst);
+            inst &= inst - 1u;
+            const float4 *rec = K.tlas_heads + TLAS_HEAD_F4 * (lf.x + i);
+            const float4 a = rec[0], b = rec[1];
+            float ds, tE;
+            const RayO lr = local_ray_rows(rec[2], rec[3], rec[4], w, ds);
+            if (slab(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), lr, ANY ? tMax * ds : T_FAR, tE))
+                mask |= 1u << i;
+        }
+    }
+    // the k-th hit of every lane, k = 0, 1, ...: ballot / prefix-sum compaction into the pair list (a leaf holds at
+    // most 17 meshes of which a ray's root tests pass one or two)
+    for (;;) {
+        const bool more = mask != 0u;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(more);
+        if (!bal)
+            break;
+        if (more) {
+            const int i = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)slot << 6) | ((uint32_t)i << 8));
+        }
+        base += __builtin_popcountll(bal);
     }
     return base;
 }
 
-PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
+// One fill: up to TLAS_SLOTS times every lane walks the TLAS to its next leaf (near child first, culling with the closest
+// hit it knows) and the leaf's root-box tests append pairs -- until the list holds TLAS_FILL_TARGET pairs or no lane
+// can advance.  The second and later leaves of a fill are walked with a limit that the first one may still lower:
+// a SUPERSET of what the reference visits, in the same order (the near/far order of two children that are both hit
+// does not depend on the limit).  Child boxes lie inside their parent's (exact min/max unions), and the slab
+// arithmetic is monotone in the box, so a node's entry distance is never below its ancestors': the reference visits a
+// leaf of that superset iff the leaf's own entry distance is below the limit at that moment.  After the queue run the
+// fill's leaves are therefore replayed in order: entry < best ? merge its minimum with strict `<` : skip it.  Stack
+// entries the reference would not have pushed fail the same test when they are popped.
+PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, CycleAcc &cyc) {
     const RayO w = make_ray(o, d);
     float tE;
     bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, T_FAR, tE);
@@ -833,6 +918,7 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
     best.u = best.v = 0.0f;
     best.mesh = best.slot = -1;
     int tcur = K.tlas_root_ref, tsp = 0;
+    float tcur_e = 0.0f; // entry distance of the node `tcur`
     bool need_pop = false;
     auto pop_t = [&]() { // the next TLAS subtree that can still hold a closer hit (E1)
         t_active = false;
@@ -841,56 +927,100 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
             const uint2 e = L.tstack[tsp * 64 + lane];
             if (__uint_as_float(e.y) < best.t) {
                 tcur = (int)e.x;
+                tcur_e = __uint_as_float(e.y);
                 t_active = true;
                 break;
             }
         }
     };
     for (;;) {
-        int2 lf = make_int2(0, 0);
-        bool has = false;
-        if (need_pop)
-            pop_t();
-        while (t_active && !has) {
-            if (tcur >= 0) {
-                const float4 n0 = K.tlas_nodes[tcur * 4 + 0], n1 = K.tlas_nodes[tcur * 4 + 1], n2 = K.tlas_nodes[tcur * 4 + 2],
-                             n3 = K.tlas_nodes[tcur * 4 + 3];
-                float tL, tR;
-                const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, best.t, tL);
-                const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, best.t, tR);
-                const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
-                if (hL || hR) {
-                    const bool nearL = hL && (!hR || tL <= tR);
-                    if (nearL ? hR : hL) {
-                        L.tstack[tsp * 64 + lane] = make_uint2((uint32_t)(nearL ? Rr : Lr), __float_as_uint(nearL ? tR : tL));
-                        ++tsp;
+        int base = 0, ns = 0;
+        float se[TLAS_SLOTS];
+        int sx[TLAS_SLOTS];
+#pragma unroll
+        for (int k = 0; k < TLAS_SLOTS; ++k) {
+            se[k] = 0.0f;
+            sx[k] = 0;
+        }
+#pragma unroll
+        for (int step = 0; step < TLAS_SLOTS; ++step) {
+            int2 lf = make_int2(0, 0);
+            bool has = false;
+            const unsigned long long t_walk = TS_NOW();
+            if (need_pop)
+                pop_t();
+            while (t_active && !has) {
+                if (tcur >= 0) {
+                    const float4 n0 = K.tlas_nodes[tcur * 4 + 0], n1 = K.tlas_nodes[tcur * 4 + 1], n2 = K.tlas_nodes[tcur * 4 + 2],
+                                 n3 = K.tlas_nodes[tcur * 4 + 3];
+                    float tL, tR;
+                    const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, best.t, tL);
+                    const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, best.t, tR);
+                    const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+                    if (hL || hR) {
+                        const bool nearL = hL && (!hR || tL <= tR);
+                        if (nearL ? hR : hL) {
+                            L.tstack[tsp * 64 + lane] = make_uint2((uint32_t)(nearL ? Rr : Lr), __float_as_uint(nearL ? tR : tL));
+                            ++tsp;
+                        }
+                        tcur = nearL ? Lr : Rr;
+                        tcur_e = nearL ? tL : tR;
+                    } else {
+                        pop_t();
                     }
-                    tcur = nearL ? Lr : Rr;
                 } else {
-                    pop_t();
+                    lf = K.tlas_leaves[~tcur];
+                    has = true;
                 }
-            } else {
-                lf = K.tlas_leaves[~tcur];
-                has = true;
             }
+            need_pop = has;
+            TS_ADD(9, t_walk);
+            // a lane's k-th leaf of this fill sits in slot k (lanes that found none keep their count)
+            const int slot = ns;
+            if (has) {
+                L.leafx[slot * 64 + lane] = lf.x;
+                L.best[slot * 64 + lane] = ~0ull;
+#pragma unroll
+                for (int k = 0; k < TLAS_SLOTS; ++k)
+                    if (k == slot) {
+                        se[k] = tcur_e;
+                        sx[k] = lf.x;
+                    }
+                ++ns;
+            }
+            if (!__builtin_amdgcn_ballot_w64(has))
+                break;
+            const unsigned long long t_b = TS_NOW();
+            base = build_pairs_general<false>(K, L, lane, has, lf, w, T_FAR, slot, base);
+            TS_ADD(10, t_b);
+            if (base >= TLAS_FILL_TARGET)
+                break;
         }
-        need_pop = has;
-        if (!__builtin_amdgcn_ballot_w64(has))
+        if (!__builtin_amdgcn_ballot_w64(ns > 0))
             break;
-        const int P = build_pairs_general<false>(K, L, lane, has, lf, w, T_FAR);
         __syncthreads();
-        run_closest_queue<true>(K, L, lane, P, o, d);
+        const unsigned long long t_q = TS_NOW();
+        run_closest_queue<true>(K, L, lane, base, o, d);
         __syncthreads();
-        const unsigned long long key = L.best[lane];
-        __syncthreads();
-        if (has && key != ~0ull) {
-            const float t = __uint_as_float((uint32_t)(key >> 32));
-            if (t < best.t) { // strict <: an earlier leaf keeps a tie (intersection.cuh:561)
-                best.t = t;
-                best.mesh = K.tlas_mesh_ids[lf.x + (int)((key >> 24) & 0xffu)];
-                best.slot = (int)(key & 0xffffffu);
+        TS_ADD(8, t_q);
+#ifdef PT_TRAV_STATS
+        cyc.c[3] += 1; // fills (closest)
+#endif
+#pragma unroll
+        for (int k = 0; k < TLAS_SLOTS; ++k) {
+            if (k < ns && (k == 0 || se[k] < best.t)) { // (the first leaf of a fill was reached with the exact limit)
+                const unsigned long long key = L.best[k * 64 + lane];
+                if (key != ~0ull) {
+                    const float t = __uint_as_float((uint32_t)(key >> 32));
+                    if (t < best.t) { // strict <: an earlier leaf keeps a tie (intersection.cuh:561)
+                        best.t = t;
+                        best.mesh = K.tlas_mesh_ids[sx[k] + (int)((key >> 24) & 0xffu)];
+                        best.slot = (int)(key & 0xffffffu);
+                    }
+                }
             }
         }
+        __syncthreads();
     }
     best.t_local = best.t;
     if (best.mesh >= 0 && (__float_as_int(K.mesh_recs[best.mesh * MESH_REC_F4 + 1].w) & 1))
@@ -898,7 +1028,9 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
     return best;
 }
 
-PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
+// Shadow rays: the same fills with the any-hit walk (bvh_any_hit_tlas, intersection.cuh:481-524).  Nothing to replay:
+// the answer is an OR over every leaf the walk reaches, and a ray seen blocked stops walking.
+PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax, CycleAcc &cyc) {
     const RayO w = make_ray(o, d);
     float tE;
     bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, tMax, tE);
@@ -916,39 +1048,60 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
     };
     __syncthreads();
     for (;;) {
-        int2 lf = make_int2(0, 0);
-        bool has = false;
-        if (need_pop)
-            pop_t();
-        while (t_active && !has) {
-            if (tcur >= 0) {
-                const float4 n0 = K.tlas_nodes[tcur * 4 + 0], n1 = K.tlas_nodes[tcur * 4 + 1], n2 = K.tlas_nodes[tcur * 4 + 2],
-                             n3 = K.tlas_nodes[tcur * 4 + 3];
-                float tL, tR;
-                const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, tMax, tL);
-                const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, tMax, tR);
-                const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
-                if (hL && hR) {
-                    L.tstack[tsp * 64 + lane] = make_uint2((uint32_t)Rr, 0u);
-                    ++tsp;
-                    tcur = Lr;
-                } else if (hL || hR) {
-                    tcur = hL ? Lr : Rr;
+        int base = 0;
+        bool any_leaf = false;
+#pragma unroll
+        for (int step = 0; step < TLAS_SLOTS; ++step) {
+            int2 lf = make_int2(0, 0);
+            bool has = false;
+            const unsigned long long t_walk = TS_NOW();
+            if (need_pop)
+                pop_t();
+            while (t_active && !has) {
+                if (tcur >= 0) {
+                    const float4 n0 = K.tlas_nodes[tcur * 4 + 0], n1 = K.tlas_nodes[tcur * 4 + 1], n2 = K.tlas_nodes[tcur * 4 + 2],
+                                 n3 = K.tlas_nodes[tcur * 4 + 3];
+                    float tL, tR;
+                    const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, tMax, tL);
+                    const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, tMax, tR);
+                    const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+                    if (hL && hR) {
+                        L.tstack[tsp * 64 + lane] = make_uint2((uint32_t)Rr, 0u);
+                        ++tsp;
+                        tcur = Lr;
+                    } else if (hL || hR) {
+                        tcur = hL ? Lr : Rr;
+                    } else {
+                        pop_t();
+                    }
                 } else {
-                    pop_t();
+                    lf = K.tlas_leaves[~tcur];
+                    has = true;
                 }
-            } else {
-                lf = K.tlas_leaves[~tcur];
-                has = true;
             }
+            need_pop = has;
+            TS_ADD(9, t_walk);
+            if (has)
+                L.leafx[step * 64 + lane] = lf.x; // (every lane uses slot `step` here: no per-slot results to keep apart)
+            if (!__builtin_amdgcn_ballot_w64(has))
+                break;
+            any_leaf = true;
+            const unsigned long long t_b = TS_NOW();
+            base = build_pairs_general<true>(K, L, lane, has, lf, w, tMax, step, base);
+            TS_ADD(10, t_b);
+            if (base >= TLAS_FILL_TARGET)
+                break;
         }
-        need_pop = has;
-        if (!__builtin_amdgcn_ballot_w64(has))
+        if (!any_leaf)
             break;
-        const int P = build_pairs_general<true>(K, L, lane, has, lf, w, tMax);
         __syncthreads();
-        run_any_queue<true>(K, L, lane, P, o, d);
+        const unsigned long long t_q = TS_NOW();
+        run_any_queue<true>(K, L, lane, base, o, d);
         __syncthreads();
+        TS_ADD(8, t_q);
+#ifdef PT_TRAV_STATS
+        cyc.c[7] += 1; // fills (any)
+#endif
         if (L.occ[lane] != 0u)
             t_active = need_pop = false; // blocked: nothing more to look for
         __syncthreads();
@@ -956,22 +1109,29 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
     return alive && (L.occ[lane] != 0u);
 }
 
+} // namespace pt
+#include "pt_merged.hip.h"
+namespace pt {
+
 // ---------------------------------------------------------------------------------
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 3
 #endif
 // PMODE 0: lock-step mesh loop; 1: pair compaction, single-leaf BLASes (triangles staged in LDS);
-//       2: pair compaction, general BLASes (per-lane traversal, LDS stacks)
+//       2: pair compaction, general BLASes (per-lane traversal, LDS stacks); 3: the same behind a real TLAS, in rounds;
+//       4: as 2 with ONE traversal per iteration: a light sample's shadow ray rides with the next extension ray
+//          (pt_merged.hip.h)
 template <int GEOM, bool FULL, int PMODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, 8))) void path_trace_kernel(const KParams K) {
     extern __shared__ uint2 lds_raw[];
     const int lane = threadIdx.x;
     LdsStack stk{lds_raw + lane};
     PairLds PL{};
+    constexpr bool MERGED = (PMODE == 4);
     if (PMODE) {
         const int staged = (PMODE == 1) ? K.pair_tri_slots : 0;
         PL = carve_pair_lds((void *)lds_raw, staged, PMODE == 3 ? 0 : K.pair_meshes, PMODE >= 2 ? K.stack_entries : 0,
-                            PMODE == 3 ? K.tlas_max_leaf : 0, PMODE == 3 ? K.tlas_depth : 0);
+                            PMODE == 3 ? K.tlas_max_leaf : 0, PMODE == 3 ? K.tlas_depth : 0, MERGED ? K.pair_cap : 0);
         const int2 lf = PMODE == 3 ? make_int2(0, 0) : K.tlas_leaves[~K.tlas_root_ref];
         if (PMODE == 1) {
             // mesh i's packets start 2*i float4 (32 B) later than in the arena: with 48-B packets
@@ -987,6 +1147,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         for (int i = lane; PMODE != 3 && i < K.pair_meshes; i += 64) {
             const int m = K.tlas_mesh_ids[lf.x + i];
             const MeshHead mh = load_mesh_head(K, m);
+            PL.meshbox[2 * i] = K.mesh_recs[m * MESH_REC_F4 + 0];
+            PL.meshbox[2 * i + 1] = K.mesh_recs[m * MESH_REC_F4 + 1];
             if (PMODE == 1) {
                 const int2 leaf = K.leaves[~mh.root_ref];
                 PL.meshtab[i] = make_int4(leaf.x, leaf.y, mh.flags, m);
@@ -998,15 +1160,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     }
     const int tile = blockIdx.x;
     const int tx = tile % K.tiles_x, ty = tile / K.tiles_x;
-    const int x = tx * 8 + (lane & 7);
-    const int yl = ty * 8 + (lane >> 3);
-    const bool inside = (x < K.width) && (yl < K.rows);
-    const int y = K.y0 + yl;
+    // Registers are what this kernel runs out of (128 per lane at four waves per SIMD; what does not fit is spilled to
+    // scratch, and a reload is a trip to the L2).  State that is only touched when a path starts or ends stays out of
+    // them: the pixel's coordinates are recomputed from the lane id where they are needed (the empty asm keeps the
+    // compiler from hoisting them back into the loop's live set), the ray counters are wave totals in scalar registers.
+    // (The running sum of the samples was tried in the pixel's own accum words, read-modify-write at the end of a
+    // sample: three registers fewer, but a dependent global load in most iterations -- Cornell 2.40 -> 2.54 ms.)
+    auto px = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return tx * 8 + (l & 7);
+    };
+    auto pyl = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return ty * 8 + (l >> 3);
+    };
+    auto pidx = [&]() { return (size_t)pyl() * K.width + px(); };
+    const bool inside = (px() < K.width) && (pyl() < K.rows);
     const size_t npix = K.rng_plane;
-    const size_t idx = (size_t)yl * K.width + x;
 
     Rng rng = {0, 0, 0, 0, 0, 0};
     if (inside) {
+        const size_t idx = pidx();
         rng.d = K.rng[idx];
         rng.v0 = K.rng[npix + idx];
         rng.v1 = K.rng[2 * npix + idx];
@@ -1014,9 +1190,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         rng.v3 = K.rng[4 * npix + idx];
         rng.v4 = K.rng[5 * npix + idx];
     }
-
     f3 avg_color = mk3(0.0f);
-    uint32_t n_ext = 0, n_shadow = 0;
+    auto close_sample = [&](f3 a) { avg_color = avg_color + a; }; // scene_kernels.cuh:171-176
+    uint32_t n_ext = 0, n_shadow = 0; // wave totals (uniform)
 
     int s = inside ? 0 : K.spp;
     int bounce = 0;
@@ -1024,8 +1200,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     f3 ro = mk3(0.0f), rd = mk3(0.0f);
     bool ray_spec = true, prev_was_specular = true;
     f3 throughput = mk3(1.0f), acc = mk3(0.0f);
+    // PMODE 4: the light sample parked with its shadow ray until the next traversal has answered its visibility
+    bool pending = false, fin = false;
+    f3 pend = mk3(0.0f), park_o = mk3(0.0f), park_d = mk3(0.0f, 0.0f, 1.0f);
+    float park_tmax = 0.0f;
 
-    while (__builtin_amdgcn_ballot_w64(s < K.spp)) {
+    CycleAcc cyc;
+    const unsigned long long t_kernel = TS_NOW();
+    while (__builtin_amdgcn_ballot_w64(s < K.spp || (MERGED && pending))) {
         const bool live = s < K.spp;
 #ifdef PT_TRAV_STATS
         {
@@ -1038,6 +1220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
 #endif
         // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
         if (live && fresh) {
+            const int x = px(), y = K.y0 + pyl();
             float tjx, tjy, bnx, bny;
             taa_jitter(K.frame_count + s, tjx, tjy);
             blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);
@@ -1065,16 +1248,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
             ray_spec = true;
             prev_was_specular = true;
             throughput = mk3(1.0f);
-            acc = mk3(0.0f);
+            if (!MERGED) // (PMODE 4 clears `acc` when it closes a sample: the previous one may still be open here)
+                acc = mk3(0.0f);
             bounce = 0;
             fresh = false;
         }
 
-        // ---- [B] closest hit, all live lanes together
-        const Hit h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd)
-                      : (PMODE == 2) ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
-                      : (PMODE == 3) ? closest_hit_pairs_tlas(K, PL, lane, live, ro, rd)
-                                     : closest_hit<GEOM>(K, live, ro, rd, stk);
+        // ---- [B] closest hit, all live lanes together (PMODE 4: and the parked shadow rays in the same traversal)
+        Hit h;
+        if (MERGED) {
+            bool blocked = false;
+            const unsigned long long t_tr = TS_NOW();
+            trace_merged(K, PL, lane, live, ro, rd, pending, park_o, park_d, park_tmax, h, blocked, cyc);
+            TS_ADD(12, t_tr);
+            if (pending && !blocked)
+                acc = acc + pend; // the light sample of the previous vertex (path_logic.cuh:840-867), in its place
+            pending = false;
+            if (fin) { // that vertex was the last of its path
+                acc = clamp_vector_soft(acc, 100.0f);
+                close_sample(acc);
+                acc = mk3(0.0f);
+                fin = false;
+            }
+        } else {
+            const unsigned long long t_tr = TS_NOW();
+            h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd)
+                : (PMODE == 2) ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
+                : (PMODE == 3) ? closest_hit_pairs_tlas(K, PL, lane, live, ro, rd, cyc)
+                               : closest_hit<GEOM>(K, live, ro, rd, stk);
+            TS_ADD(12, t_tr);
+        }
 
         // ---- [C] first half of the shading
         bool end_path = false, shaded = false, want_shadow = false;
@@ -1084,10 +1287,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         hit.front_face = true;
         f3 L = mk3(0.0f), light_scale = mk3(0.0f), shadow_o = mk3(0.0f);
         float pdf_sample = 1.0f, shadow_tmax = 0.0f, light_att = 1.0f;
+        n_ext += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
         if (live) {
-            ++n_ext;
             if (h.mesh < 0) {
                 if (bounce == 0 && s == 0) { // G-buffer of the first sample's first hit (scene_kernels.cuh:181-193)
+                    const size_t idx = pidx();
                     K.normal[idx * 3 + 0] = 0.0f;
                     K.normal[idx * 3 + 1] = 0.0f;
                     K.normal[idx * 3 + 2] = 0.0f;
@@ -1113,6 +1317,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
                 shaded = true;
                 hit = make_surface(K, h, ro, rd, nullptr, nullptr);
                 if (bounce == 0 && s == 0) {
+                    const size_t idx = pidx();
                     K.normal[idx * 3 + 0] = hit.normal.x;
                     K.normal[idx * 3 + 1] = hit.normal.y;
                     K.normal[idx * 3 + 2] = hit.normal.z;
@@ -1177,37 +1382,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
                     light_scale = light_radiance;
                     light_att = attenuation;
                     want_shadow = true;
-                    ++n_shadow;
+                }
+            }
+        }
+        n_shadow += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow));
+
+        // ---- [C2] the light sample's value, BEFORE its visibility is known (path_logic.cuh:840-867: bsdf * radiance *
+        // attenuation / pdf, soft clamp, MIS weight): `lit_now = throughput * direct * wgt` is what a visible sample adds
+        // to `acc`, formed from the same operands in the same order as in the reference and added in the same place, so
+        // no bit changes.  A sample that adds nothing either way (outside a spot cone, BSDF zero below the horizon)
+        // needs no shadow ray: it is counted -- the reference traces it -- but not walked.
+        bool lit = false;
+        f3 lit_now = mk3(0.0f);
+        if (want_shadow) {
+            int mi = h.mesh;
+            asm volatile("" : "+v"(mi)); // (its own fetch of the material: not 22 registers live across the shadow phase)
+            const Material mat = load_material(K.materials, mi);
+            const f3 V = -rd;
+            const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
+            if (pdf_sample > 0.0f) {
+                f3 direct = bsdf * light_scale * light_att / pdf_sample;
+                direct = clamp_vector_soft(direct, 500.0f);
+                if (direct.x > 0.0f || direct.y > 0.0f || direct.z > 0.0f) {
+                    const float pdf_brdf = material_pdf<FULL>(hit, mat, V, L);
+                    const float wgt = mis_weight(pdf_sample, pdf_brdf);
+                    lit_now = throughput * direct * wgt;
+                    lit = true;
                 }
             }
         }
 
-        // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas)
-        bool in_shadow = false;
-        if (__builtin_amdgcn_ballot_w64(want_shadow)) {
-            in_shadow = (PMODE == 1)   ? any_hit_pairs(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
-                        : (PMODE == 2) ? any_hit_pairs_dyn(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
-                        : (PMODE == 3) ? any_hit_pairs_tlas(K, PL, lane, want_shadow, shadow_o, L, shadow_tmax)
-                                       : any_hit<GEOM>(K, want_shadow, shadow_o, L, shadow_tmax, stk);
+        // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas); PMODE 4 parks them instead and
+        // walks them with the next extension rays
+        const unsigned long long t_sh = TS_NOW();
+        if (MERGED) {
+            if (lit) {
+                pend = lit_now;
+                park_o = shadow_o;
+                park_d = L;
+                park_tmax = shadow_tmax;
+                pending = true;
+            }
+        } else if (__builtin_amdgcn_ballot_w64(lit)) {
+            const bool in_shadow = (PMODE == 1)   ? any_hit_pairs(K, PL, lane, lit, shadow_o, L, shadow_tmax)
+                                   : (PMODE == 2) ? any_hit_pairs_dyn(K, PL, lane, lit, shadow_o, L, shadow_tmax)
+                                   : (PMODE == 3) ? any_hit_pairs_tlas(K, PL, lane, lit, shadow_o, L, shadow_tmax, cyc)
+                                                  : any_hit<GEOM>(K, lit, shadow_o, L, shadow_tmax, stk);
+            if (lit && !in_shadow)
+                acc = acc + lit_now;
         }
+        TS_ADD(13, t_sh);
 
         // ---- [E] second half of the shading
         if (shaded) {
             const Material mat = load_material(K.materials, h.mesh);
-            const f3 V = -rd;
-            if (want_shadow && !in_shadow) {
-                const float attenuation = light_att;
-                const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
-                if (pdf_sample > 0.0f) {
-                    f3 direct = bsdf * light_scale * attenuation / pdf_sample;
-                    direct = clamp_vector_soft(direct, 500.0f);
-                    if (direct.x > 0.0f || direct.y > 0.0f || direct.z > 0.0f) {
-                        const float pdf_brdf = material_pdf<FULL>(hit, mat, V, L);
-                        const float wgt = mis_weight(pdf_sample, pdf_brdf);
-                        acc = acc + throughput * direct * wgt;
-                    }
-                }
-            }
             f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
             bool is_specular = false;
             if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular)) {
@@ -1238,14 +1466,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
             }
         }
         if (live && end_path) {
-            acc = clamp_vector_soft(acc, 100.0f);
-            avg_color = avg_color + acc;
+            if (MERGED && pending) {
+                fin = true; // closed after the next traversal, once the parked light sample is in
+            } else {
+                acc = clamp_vector_soft(acc, 100.0f);
+                close_sample(acc);
+                if (MERGED)
+                    acc = mk3(0.0f);
+            }
             ++s;
             fresh = true;
         }
     }
 
+    TS_ADD(14, t_kernel);
+    cyc.flush(lane);
     if (inside) {
+        const int x = px(), yl = pyl();
+        const size_t idx = (size_t)yl * K.width + x;
         K.rng[idx] = rng.d;
         K.rng[npix + idx] = rng.v0;
         K.rng[2 * npix + idx] = rng.v1;
@@ -1268,12 +1506,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         }
     }
     if (K.counters) {
-        uint32_t a = n_ext, b = n_shadow, c = inside ? (uint32_t)K.spp : 0u;
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off);
-            b += __shfl_xor(b, off);
-            c += __shfl_xor(c, off);
-        }
+        const uint32_t a = n_ext, b = n_shadow,
+                       c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside)) * (uint32_t)K.spp;
         // one slot of three counters per workgroup, plain read-modify-write (only this workgroup touches
         // it within a launch; launches are ordered).  Three atomics per wave on three shared addresses
         // serialised at the L2 atomic unit: 97 K of them took 1.2 ms per 1080p frame -- hidden behind a

@@ -63,6 +63,8 @@ struct ptrt_ctx {
            *d_materials = nullptr, *d_lights = nullptr;
     int2 *d_leaves = nullptr, *d_tlas_leaves = nullptr;
     int *d_tlas_mesh_ids = nullptr;
+    float4 *d_tlas_heads = nullptr; // mesh-record heads in TLAS-leaf order (PMODE 3), gathered before each frame
+    int n_tlas_index = 0;
     std::vector<float4> h_mesh_recs;
     std::vector<unsigned char> h_shadow_skip; // per material: transmission > 0.5
     int n_meshes = 0, n_materials = 0, n_lights = 0;
@@ -152,6 +154,7 @@ struct ptrt_ctx {
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
+    int merged = 0; // option: PMODE 4 (one traversal per loop iteration) where PMODE 2 applies; measured equal to PMODE 2 on the showcase frame, 10 % slower on the fluid frame
     bool timed = false;
 };
 
@@ -405,6 +408,9 @@ int upload_tlas(ptrt_ctx *c, int mesh_count, const ptrt_bvh_node *tlas_nodes, in
         return rc;
     if (int rc = upload(c, c->d_tlas_mesh_ids, tids))
         return rc;
+    dfree(c->d_tlas_heads);
+    HIP_TRY(c, hipMalloc((void **)&c->d_tlas_heads, (size_t)tlas_index_count * pt::TLAS_HEAD_F4 * sizeof(float4)));
+    c->n_tlas_index = tlas_index_count;
     c->tlas_root_ref = troot;
     c->tlas_single_leaf = troot < 0;
     c->pair_meshes = troot < 0 ? tleaves[~troot].y : 0;
@@ -427,6 +433,7 @@ void free_scene(ptrt_ctx *c) {
     dfree(c->d_leaves);
     dfree(c->d_tlas_leaves);
     dfree(c->d_tlas_mesh_ids);
+    dfree(c->d_tlas_heads);
     dfree(c->d_tlas_root_box);
     dfree(c->d_verts);
     dfree(c->d_slot_face);
@@ -471,6 +478,7 @@ int set_device(ptrt_ctx *c) {
     return PTRT_OK;
 }
 
+int merged_pair_cap(const ptrt_ctx *c);
 pt::KParams make_params(ptrt_ctx *c) {
     pt::KParams K{};
     K.mesh_recs = c->d_mesh_recs;
@@ -480,6 +488,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.tlas_nodes = c->d_tlas_nodes;
     K.tlas_leaves = c->d_tlas_leaves;
     K.tlas_mesh_ids = c->d_tlas_mesh_ids;
+    K.tlas_heads = c->d_tlas_heads;
     K.materials = c->d_materials;
     K.lights = c->d_lights;
     K.blue_noise = c->d_blue;
@@ -495,6 +504,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.tlas_depth = c->tlas_depth < 1 ? 1 : c->tlas_depth;
     K.pair_split = (c->pair_split && !c->any_transform) ? 1 : 0;
     K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
+    K.pair_cap = merged_pair_cap(c);
     // the compacted leaf phase lists up to 64 x (largest leaf) tests in LEAF_PAIR_BYTES - 512 bytes of LDS: the reference
     // builder's leaves (<= 17 triangles) fit; a scene built with a larger leaf target walks its leaves lane by lane
     K.leaf_pairs = (c->leaf_pairs && (size_t)c->pair_max_leaf * 64 <= (size_t)pt::LEAF_PAIR_BYTES - 512) ? 1 : 0;
@@ -542,11 +552,25 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
 
 // in-wave (ray, mesh) pair compaction needs every BLAS to be one leaf and the staged
 // triangle packets to fit a modest LDS budget
+// PMODE 4 keeps extension and shadow pairs in one list: 64 * meshes entries always fit the extension pairs; the
+// shadow pairs get what is left of a 10-KB LDS budget (16 waves per CU), at least 64 (one mesh per pass), at most
+// another 64 * meshes (everything in one pass)
+int merged_pair_cap(const ptrt_ctx *c) {
+    const size_t rest = (size_t)c->pair_meshes * 48 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
+    const int lo = 64 * c->pair_meshes + 64, hi = 128 * c->pair_meshes;
+    int cap = rest < 10240 ? (int)((10240 - rest) / 2) / 64 * 64 : 0;
+    cap = cap < lo ? lo : cap;
+    return cap > hi ? hi : cap;
+}
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
+    if (pmode == 4)
+        return (size_t)c->pair_meshes * 48 + 512 + 256 + (size_t)merged_pair_cap(c) * 2 +
+               (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
     if (pmode == 3) // no mesh table; pair list for one TLAS leaf per ray; TLAS stack + the rays' leaf starts
-        return (size_t)c->tlas_max_leaf * 128 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) +
-               (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 + 256 + pt::LEAF_PAIR_BYTES;
-    const size_t common = (size_t)c->pair_meshes * 16 + (size_t)c->pair_meshes * (pmode == 1 ? 256 : 128) +
+        return ((size_t)c->tlas_max_leaf * 64 + pt::TLAS_FILL_TARGET) * 2 + 512 * pt::TLAS_SLOTS + 256 +
+               (size_t)c->stack_entries * 64 * sizeof(uint2) + (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 +
+               256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES;
+    const size_t common = (size_t)c->pair_meshes * 48 + (size_t)c->pair_meshes * (pmode == 1 ? 256 : 128) + // (mesh table + staged heads)
                           (pmode == 1 ? 6 * 256 : 0) + 512 + 256; // (ray planes: PMODE 1 only)
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
@@ -556,12 +580,16 @@ int pair_mode(const ptrt_ctx *c, int geom) {
     if (!c->pair_trace)
         return 0;
     if (geom == 2) // a real TLAS: rounds of one leaf per ray (pt_render.hip.h)
-        return (c->tlas_max_leaf > 0 && c->tlas_max_leaf < 256 && c->pair_tri_slots < (1 << 24) && pair_lds_bytes(c, 3) <= 40 * 1024)
+        return (c->tlas_max_leaf > 0 && c->tlas_max_leaf <= 32 && c->pair_tri_slots < (1 << 24) && pair_lds_bytes(c, 3) <= 40 * 1024)
                    ? 3 : 0;
     if (c->pair_meshes <= 0)
         return 0;
     if (geom == 0 && c->pair_meshes < 65536 && c->pair_max_leaf < 65536 && pair_lds_bytes(c, 1) <= 40 * 1024)
         return 1;
+    // (PMODE 4's compacted leaf phase is not optional: scenes with leaves beyond its list keep PMODE 2)
+    if (geom <= 1 && c->merged && c->leaf_pairs && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) &&
+        (size_t)c->pair_max_leaf * 64 <= (size_t)pt::LEAF_PAIR_BYTES - 512 && pair_lds_bytes(c, 4) <= 40 * 1024)
+        return 4;
     if (geom <= 1 && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) && pair_lds_bytes(c, 2) <= 40 * 1024)
         return 2;
     return 0;
@@ -1731,6 +1759,11 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const bool full = c->mats_full || c->force_full;
     const int pmode = pair_mode(c, geom);
     const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
+    if (pmode == 3) { // (outside the timed kernel: a 136-thread copy)
+        hipLaunchKernelGGL(pt::gather_tlas_heads_kernel, dim3((c->n_tlas_index + 63) / 64), dim3(64), 0, c->stream,
+                           c->d_mesh_recs, c->d_tlas_mesh_ids, c->n_tlas_index, c->d_tlas_heads);
+        HIP_TRY(c, hipGetLastError());
+    }
     const int slot = (int)(c->launches % EV_RING);
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
     c->last_mode = 0;
@@ -1744,6 +1777,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         c->last_mode = 1;
     } else if (pmode == 1)
         launch_trace<0, 1>(c, K, full, grid, lds);
+    else if (pmode == 4)
+        launch_trace<1, 4>(c, K, full, grid, lds);
     else if (pmode == 2)
         launch_trace<1, 2>(c, K, full, grid, lds);
     else if (pmode == 3)
@@ -2246,7 +2281,9 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         if (value < 0 || value > 64)
             return fail(c, PTRT_E_INVALID, "steal must be 0..64");
         c->steal = (int)value;
-    } else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
+    } else if (n == "merged") // PMODE 4 instead of 2: shadow rays ride with the next extension rays (A/B, tests)
+        c->merged = value ? 1 : 0;
+    else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
         c->leaf_pairs = value ? 1 : 0;
     else if (n == "pair_split") // PMODE 1: 0 = one lane per pair also in batches that do not fill the wave (A/B, tests)
         c->pair_split = value ? 1 : 0;

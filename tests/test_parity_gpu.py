@@ -168,15 +168,21 @@ def test_showcase_small(P, O, blue_noise):
     s.close()
 
 
+@pytest.mark.parametrize("merged", [1, 0])
 @pytest.mark.parametrize("fetch_min,leaf_pairs,leaf_min,steal", [(0, 0, 64, 0), (1, 1, 1, 1), (16, 0, 8, 2), (16, 1, 8, 0),
                                                                  (16, 1, 4, 2), (48, 1, 64, 8), (64, 1, 24, 1)])
-def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, leaf_min, steal):
-    """PMODE 2 (deep BLASes behind a single-leaf TLAS): static 64-pair batches (0) and the dynamic
+def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, leaf_min, steal, merged):
+    """PMODE 4 / PMODE 2 (deep BLASes behind a single-leaf TLAS; merged=1: one traversal per iteration, the parked
+    shadow rays riding with the next extension rays -- needs leaf_pairs; merged=0: closest-hit and any-hit phases):
+    static 64-pair batches (0) and the dynamic
     refill at every threshold, with the leaf phase lane by lane (0) or as compacted (lane, triangle)
     pairs (1), the node loop ending once leaf_min lanes wait at a leaf, and idle lanes stealing shadow-ray subtrees (steal > 0),
     give the oracle's bits -- showcase materials, plus instanced meshes."""
+    if merged and not leaf_pairs:
+        pytest.skip("the merged traversal always uses the compacted leaf phase")
     s = P.Scene(96, 64)
     P.scenes.showcase(s, segments=12)
+    s.set_option("merged", merged)
     s.set_option("fetch_min", fetch_min)
     s.set_option("leaf_pairs", leaf_pairs)
     s.set_option("leaf_min", leaf_min)
@@ -191,6 +197,7 @@ def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, l
     s.setRotation(extra, (0.3, 0.5, 0.1))
     s.setInstanceScale(extra, (1.5, 0.7, 1.2))
     s.setBVHLeafTarget(2, 0)
+    s.set_option("merged", merged)
     s.set_option("fetch_min", fetch_min)
     s.set_option("leaf_pairs", leaf_pairs)
     s.set_option("leaf_min", leaf_min)

@@ -47,11 +47,23 @@ if any(kv.startswith("async_lanes=1") for kv in sys.argv[5:]):
     sys.exit(0)
 for name, b in (("closest", 0), ("any-hit", 8)):
     calls, pairs, nw, nl, lp, tw, tl, outer = v[b:b + 8]
-    if not calls:
+    if not calls or (b == 8 and v[14]):  # (the merged traversal keeps its cycle counts in 8..15)
         continue
     print(f"{name}: calls {calls}  pairs/call {pairs / calls:.1f}  outer iters/call {outer / calls:.2f}")
     print(f"   node steps: {nw / calls:.1f} wave-iterations/call, lanes busy {100.0 * nl / max(1, nw * 64):.1f} %  "
           f"({nl / max(1, pairs):.1f} nodes per pair)")
     print(f"   leaf phases/call {lp / calls:.1f}; triangle loop: {tw / calls:.1f} wave-iterations/call, lanes busy "
           f"{100.0 * tl / max(1, tw * 64):.1f} %  ({tl / max(1, pairs):.1f} triangles per pair)")
+if v[14] and v[11] and v[11] < 1e9 and v[9]:  # PMODE 3 rounds (slot 11 / 15 hold round counts)
+    tot = v[14]
+    print(f"PMODE 3: wave cycles {tot:.4g}; closest-hit trace {100.0 * v[12] / tot:.1f} %, shadow trace {100.0 * v[13] / tot:.1f} %, rest {100.0 * (tot - v[12] - v[13]) / tot:.1f} %")
+    print(f"   inside the traces: TLAS walks {100.0 * v[9] / tot:.1f} %, pair builds {100.0 * v[10] / tot:.1f} %, queue runs {100.0 * v[8] / tot:.1f} %")
+    print(f"   rounds per loop iteration: closest {v[11] / max(1, v[16]):.2f}, shadow {v[15] / max(1, v[16]):.2f}")
+elif v[14]:  # merged traversal, instrumented build: where a wave's cycles go (s_memtime, summed over waves)
+    tot = v[14]
+    print(f"wave cycles {tot:.4g} = {tot / 32400 / 2.4e3:.0f} us per wave at 2.4 GHz: trace_merged {100.0 * v[12] / tot:.1f} %  "
+          f"(queue run {100.0 * v[8] / tot:.1f} %: node loops {100.0 * v[9] / tot:.1f} %, leaf blocks {100.0 * v[10] / tot:.1f} %, "
+          f"refill+steal {100.0 * v[11] / tot:.1f} %), everything else {100.0 * (tot - v[12]) / tot:.1f} %")
+    print(f"   per node wave-iteration {v[9] / max(1, v[2]):.0f} cycles, per triangle wave-iteration {v[10] / max(1, v[5]):.0f} cycles "
+          f"(leaf block incl. prefix sums), per outer iteration refill+steal {v[11] / max(1, v[7]):.0f} cycles")
 print(f"persistent loop: {v[16]} iterations, live lanes {100.0 * v[17] / max(1, v[16] * 64):.1f} %")

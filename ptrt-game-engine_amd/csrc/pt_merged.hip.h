@@ -244,14 +244,8 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 first = lf.x;
                 cnt = lf.y;
             }
-            int incl = cnt;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if (lane >= off)
-                    incl += v;
-            }
-            const int start = incl - cnt;
-            const int T = __builtin_amdgcn_readlane(incl, 63);
+            int start, T;
+            leaf_prefix(cnt, start, T);
             if (atleaf) {
                 L.lkey[lane] = ~0ull;
                 for (int i = 0; i < cnt; ++i)

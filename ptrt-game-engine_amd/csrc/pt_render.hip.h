@@ -38,7 +38,9 @@
 
 namespace pt {
 
+struct CycleAcc;
 struct PairLds {
+    CycleAcc *cyc;            // (stats build: the kernel's cycle accumulator)
     float4 *tris;             // pair_tri_slots * 3
     int4 *meshtab;            // per mesh order: {first slot, count, flags, mesh id}
     float4 *meshbox;          // per mesh order: {bmin, root ref}, {bmax, flags}: the mesh record's head, staged once
@@ -97,7 +99,7 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
 // wave is in each loop of the PMODE 2 traversals.  [0..7] closest, [8..15] any-hit:
 // calls, pairs, node wave-iterations, node lane-steps, leaf phases, triangle wave-iterations,
 // triangle lane-tests, outer iterations; [16] persistent-loop iterations, [17] live lanes in them.
-__device__ unsigned long long g_trav_stats[24];
+__device__ unsigned long long g_trav_stats[32]; // [0..7] closest, [8..15] any-hit, [16..17] loop, [24..31] cycles (CycleAcc)
 #ifdef PT_TRAV_STATS
 struct TravStats {
     unsigned v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -125,11 +127,12 @@ struct CycleAcc {
     PT_DEV void flush(int lane) {
         if (lane == 0)
             for (int i = 0; i < 8; ++i)
-                atomicAdd(&g_trav_stats[8 + i], c[i]);
+                atomicAdd(&g_trav_stats[24 + i], c[i]);
     }
 };
 #define TS_NOW() __builtin_readcyclecounter()
 #define TS_ADD(slot, t) (cyc.c[(slot) - 8] += __builtin_readcyclecounter() - (t))
+#define TS_ADDL(slot, t) (L.cyc->c[(slot) - 8] += __builtin_readcyclecounter() - (t))
 #else
 struct TravStats {
     PT_DEV void flush(int, int) {}
@@ -141,6 +144,7 @@ struct CycleAcc {
 };
 #define TS_NOW() 0ull
 #define TS_ADD(slot, t) (void)(t)
+#define TS_ADDL(slot, t) (void)(t)
 #endif
 
 PT_DEV void wave_lds_order() { // LDS is in order within a wave; this only pins the compiler
@@ -161,6 +165,20 @@ PT_DEV MeshHead staged_mesh_head(const PairLds &L, int i) {
     h.root_ref = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));
     h.flags = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
     return h;
+}
+
+// Exclusive prefix sum and total of the lanes' leaf sizes (< 32) by bit planes: five ballots and mbcnt pairs, no LDS --
+// the shuffle scan it replaces was six dependent ds_bpermute round trips per leaf phase.
+PT_DEV void leaf_prefix(int cnt, int &start, int &total) {
+    int st = 0, tot = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((cnt >> b) & 1);
+        st += lane_prefix(m) << b;
+        tot += __builtin_popcountll(m) << b;
+    }
+    start = st;
+    total = tot;
 }
 
 // step 1: root-box tests + ballot/prefix-sum compaction into the LDS pair list
@@ -444,6 +462,7 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
         // Inner nodes.  A lane needs ~2 node steps to its next leaf, the slowest of 64 needs ~12: the
         // descent stops as soon as K.leaf_min lanes wait at a leaf (wave-uniform loop, predicated step, so
         // the waiting lanes take part in the ballots); they are served below, pop, and rejoin it.
+        const unsigned long long t_nd = TS_NOW();
         for (;;) {
             const bool innode = active && cur >= 0;
             if (!__builtin_amdgcn_ballot_w64(innode))
@@ -471,6 +490,8 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
                 }
             }
         }
+        TS_ADDL(9, t_nd);
+        const unsigned long long t_lf = TS_NOW();
         const bool atleaf = active && cur < 0;
         if (K.leaf_pairs) {
             // Leaf phase as (lane, triangle) pairs.  Lane by lane it runs as long as the largest leaf (<= 17
@@ -484,14 +505,8 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
                 first = lf.x;
                 cnt = lf.y;
             }
-            int incl = cnt;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if (lane >= off)
-                    incl += v;
-            }
-            const int start = incl - cnt;
-            const int T = __builtin_amdgcn_readlane(incl, 63);
+            int start, T;
+            leaf_prefix(cnt, start, T);
             if (atleaf) {
                 L.lkey[lane] = ~0ull;
                 for (int i = 0; i < cnt; ++i)
@@ -557,6 +572,7 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
             }
             pop();
         }
+        TS_ADDL(10, t_lf);
         if (busy && !active) { // this pair is finished: merge it into its ray
             if (sb >= 0) {
                 const float tw = xf ? tb / dirScale : tb;
@@ -591,7 +607,9 @@ PT_DEV float winner_t_local(const KParams &K, int mesh, int slot, f3 o, f3 d) {
 PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
     const int P = build_pairs<false, true>(K, L, lane, alive, o, d, T_FAR);
     __syncthreads();
+    const unsigned long long t_q = TS_NOW();
     run_closest_queue<false>(K, L, lane, P, o, d);
+    TS_ADDL(8, t_q);
     __syncthreads();
     const unsigned long long key = L.best[lane];
     __syncthreads();
@@ -745,14 +763,8 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
                 first = lf.x;
                 cnt = lf.y;
             }
-            int incl = cnt;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if (lane >= off)
-                    incl += v;
-            }
-            const int start = incl - cnt;
-            const int T = __builtin_amdgcn_readlane(incl, 63);
+            int start, T;
+            leaf_prefix(cnt, start, T);
             if (atleaf) {
                 L.lkey[lane] = 0ull;
                 for (int i = 0; i < cnt; ++i)
@@ -820,7 +832,9 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
     const int P = build_pairs<true, true>(K, L, lane, alive, o, d, tMax);
     ((float *)L.best)[lane] = tMax;
     __syncthreads();
+    const unsigned long long t_q = TS_NOW();
     run_any_queue<false>(K, L, lane, P, o, d);
+    TS_ADDL(11, t_q);
     __syncthreads();
     const bool occluded = alive && (L.occ[lane] != 0u);
     __syncthreads();
@@ -1206,6 +1220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     float park_tmax = 0.0f;
 
     CycleAcc cyc;
+    PL.cyc = &cyc;
     const unsigned long long t_kernel = TS_NOW();
     while (__builtin_amdgcn_ballot_w64(s < K.spp || (MERGED && pending))) {
         const bool live = s < K.spp;

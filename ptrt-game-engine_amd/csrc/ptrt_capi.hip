@@ -2325,8 +2325,8 @@ int ptrt_debug_trav_stats(ptrt_ctx *c, unsigned long long *out24) {
     if (int rc = set_device(c))
         return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpyFromSymbol(out24, HIP_SYMBOL(pt::g_trav_stats), 24 * sizeof(unsigned long long)));
-    unsigned long long zero[24] = {};
+    HIP_TRY(c, hipMemcpyFromSymbol(out24, HIP_SYMBOL(pt::g_trav_stats), 32 * sizeof(unsigned long long)));
+    unsigned long long zero[32] = {};
     HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(pt::g_trav_stats), zero, sizeof(zero)));
     return PTRT_OK;
 }

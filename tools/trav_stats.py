@@ -26,7 +26,7 @@ for kv in sys.argv[5:]:
     k, _, v = kv.partition("=")
     s.set_option(k, int(v))
 buf = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 32)()
 P.lib.ptrt_debug_trav_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 P.lib.ptrt_debug_trav_stats(s.ctx, out)
 s.stats()
@@ -35,6 +35,7 @@ torch.cuda.synchronize()
 assert P.lib.ptrt_debug_trav_stats(s.ctx, out) == 0
 st = s.stats()
 v = list(out)
+cy = dict(zip((8, 9, 10, 11, 12, 13, 14, 15), v[24:32]))  # cycle slots (CycleAcc)
 print("rays", st)
 if any(kv.startswith("async_lanes=1") for kv in sys.argv[5:]):
     it, sr, sl, mr, ml, nw, nl, _, tw, tl, tr = v[:11]
@@ -47,23 +48,20 @@ if any(kv.startswith("async_lanes=1") for kv in sys.argv[5:]):
     sys.exit(0)
 for name, b in (("closest", 0), ("any-hit", 8)):
     calls, pairs, nw, nl, lp, tw, tl, outer = v[b:b + 8]
-    if not calls or (b == 8 and v[14]):  # (the merged traversal keeps its cycle counts in 8..15)
+    if not calls:
         continue
     print(f"{name}: calls {calls}  pairs/call {pairs / calls:.1f}  outer iters/call {outer / calls:.2f}")
     print(f"   node steps: {nw / calls:.1f} wave-iterations/call, lanes busy {100.0 * nl / max(1, nw * 64):.1f} %  "
           f"({nl / max(1, pairs):.1f} nodes per pair)")
     print(f"   leaf phases/call {lp / calls:.1f}; triangle loop: {tw / calls:.1f} wave-iterations/call, lanes busy "
           f"{100.0 * tl / max(1, tw * 64):.1f} %  ({tl / max(1, pairs):.1f} triangles per pair)")
-if v[14] and v[11] and v[11] < 1e9 and v[9]:  # PMODE 3 rounds (slot 11 / 15 hold round counts)
-    tot = v[14]
-    print(f"PMODE 3: wave cycles {tot:.4g}; closest-hit trace {100.0 * v[12] / tot:.1f} %, shadow trace {100.0 * v[13] / tot:.1f} %, rest {100.0 * (tot - v[12] - v[13]) / tot:.1f} %")
-    print(f"   inside the traces: TLAS walks {100.0 * v[9] / tot:.1f} %, pair builds {100.0 * v[10] / tot:.1f} %, queue runs {100.0 * v[8] / tot:.1f} %")
-    print(f"   rounds per loop iteration: closest {v[11] / max(1, v[16]):.2f}, shadow {v[15] / max(1, v[16]):.2f}")
-elif v[14]:  # merged traversal, instrumented build: where a wave's cycles go (s_memtime, summed over waves)
-    tot = v[14]
-    print(f"wave cycles {tot:.4g} = {tot / 32400 / 2.4e3:.0f} us per wave at 2.4 GHz: trace_merged {100.0 * v[12] / tot:.1f} %  "
-          f"(queue run {100.0 * v[8] / tot:.1f} %: node loops {100.0 * v[9] / tot:.1f} %, leaf blocks {100.0 * v[10] / tot:.1f} %, "
-          f"refill+steal {100.0 * v[11] / tot:.1f} %), everything else {100.0 * (tot - v[12]) / tot:.1f} %")
-    print(f"   per node wave-iteration {v[9] / max(1, v[2]):.0f} cycles, per triangle wave-iteration {v[10] / max(1, v[5]):.0f} cycles "
-          f"(leaf block incl. prefix sums), per outer iteration refill+steal {v[11] / max(1, v[7]):.0f} cycles")
+if cy[14]:  # instrumented build: where a wave's cycles go (s_memtime, summed over waves)
+    tot = cy[14]
+    pct = lambda k: 100.0 * cy[k] / tot
+    print(f"wave cycles {tot:.4g}: closest-hit (or merged) trace {pct(12):.1f} %, shadow trace {pct(13):.1f} %, "
+          f"everything else {100.0 - pct(12) - pct(13):.1f} %")
+    print(f"   inside: queue runs {pct(8):.1f} %, closest node loops {pct(9):.1f} %, closest leaf blocks {pct(10):.1f} %, "
+          f"any-hit queue runs {pct(11):.1f} %")
+    if v[2] and v[5]:
+        print(f"   per closest node wave-iteration {cy[9] / v[2]:.0f} units, per closest triangle wave-iteration {cy[10] / v[5]:.0f} units")
 print(f"persistent loop: {v[16]} iterations, live lanes {100.0 * v[17] / max(1, v[16] * 64):.1f} %")

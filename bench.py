@@ -9,8 +9,18 @@ keyed by the global pixel index, so the image is bit-identical to the 1-GPU fram
 scaling.  Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps 30 --warmup 3
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
          --master-port P bench.py --gpus N --steps K --warmup W
+
+`--config` picks another BASELINE configuration as the measured workload (the headline stays configs[1]):
+  cornell1080   configs[1]  Cornell box 1920x1080, 4 spp, 4 bounces                (default)
+  showcase1080  configs[2]  showcase scene (100,820 triangles) 1920x1080, 4 spp
+  showcase4k8   configs[3]  showcase scene 3840x2160, 8 spp (the frame the 8-GPU split is quoted on)
+  fluid         configs[4]  water refit + trace, 1920x1080, 2 spp
+  million                   8 x 125,000-triangle spheres: the workload of the reference's published fps
+                            (Test game screenshots/readme.txt), with --preset fast|performance|balanced|quality|ultra
+Every default run also measures configs[3] over the same N ranks for a few frames and reports it in the extra field
+"configs3" of the line, so a scaling run over N = 1, 2, 4, 8 yields BASELINE's curve without changing the headline.
 """
 import argparse
 import json
@@ -23,10 +33,19 @@ sys.path.insert(0, os.path.join(ROOT, "ptrt-game-engine_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PIXEL = 143.0   # RNG 48R+48W, accum 12W, normal 12W, depth 4W, id 4W, tonemap 12R+3W
+SIMDS, CLOCK_HZ, VALU_CYCLES = 256 * 4, 2.4e9, 2.0  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU op issues over 2 cycles
+
+CONFIGS = {
+    "cornell1080": dict(scene="cornell", width=1920, height=1080, spp=4, depth=4),
+    "showcase1080": dict(scene="showcase", width=1920, height=1080, spp=4, depth=4),
+    "showcase4k8": dict(scene="showcase", width=3840, height=2160, spp=8, depth=4),
+    "fluid": dict(scene="fluid", width=1920, height=1080, spp=2, depth=4),
+    "million": dict(scene="million", width=1920, height=1080, spp=1, depth=4),
+}
 
 
-def build_scene(P, name, W, H, y0, rows, device):
-    s = P.Scene(W, H, tile_y0=y0, tile_rows=rows, device=device)
+def build_scene(P, name, W, H, y0, rows, device, interleave=None):
+    s = P.Scene(W, H, tile_y0=y0, tile_rows=rows, device=device, interleave=interleave)
     if name == "cornell":
         P.scenes.cornell(s)
     elif name == "showcase":
@@ -35,6 +54,10 @@ def build_scene(P, name, W, H, y0, rows, device):
         P.scenes.many(s, 128, sphere_segments=32)
     elif name == "fluid":
         s.water_mesh, _ = P.scenes.fluid(s, cells=256, t=0.0)
+    elif name == "million":
+        P.scenes.million(s)
+    elif name == "matrix":  # the reference application's scene 10 (app_utils.cuh:729-795)
+        P.scenes.material_matrix(s)
     else:
         raise SystemExit(f"unknown scene {name}")
     s.setDenoiserEnabled(False)
@@ -43,26 +66,217 @@ def build_scene(P, name, W, H, y0, rows, device):
 
 
 def cpu_baseline(P, scene_name, W, H, spp, depth, frame, threads):
-    """The oracle ("port" of the reference path; the reference has no CPU renderer) timed on this
-    box's host cores over a bounded sample: the full frame once for Cornell."""
+    """The oracle ("port" of the reference path; the reference has no CPU renderer) timed on this box's host cores
+    over a bounded sample of the same frame: all-core on a band of rows, and one core on a narrower band."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     s = build_scene(P, scene_name, W, H, 0, 0, P.HOST_ONLY)
     s.setPerfSamplesPerPixel(spp)
     s.setMaxBounceDepth(depth)
     desc = s.flatten()
-    rows = H if scene_name == "cornell" else max(8, H // 4)
-    y0 = (H - rows) // 2
-    rng = O.xorwow_init(P.DEFAULT_SEED, y0 * W, rows * W)
     bn = P.blue_noise_table()
-    t0 = time.perf_counter()
-    r = O.render(desc, W, H, spp, depth, frame, bn, rng, tile_y0=y0, tile_rows=rows, threads=threads)
-    dt = time.perf_counter() - t0
-    rays = r["stats"]["extension_rays"] + r["stats"]["shadow_rays"]
+
+    def sample(rows, nthreads):
+        y0 = (H - rows) // 2
+        rng = O.xorwow_init(P.DEFAULT_SEED, y0 * W, rows * W)
+        t0 = time.perf_counter()
+        r = O.render(desc, W, H, spp, depth, frame, bn, rng, tile_y0=y0, tile_rows=rows, threads=nthreads)
+        dt = time.perf_counter() - t0
+        rays = r["stats"]["extension_rays"] + r["stats"]["shadow_rays"]
+        return rays, dt, y0
+
+    rows = H if scene_name == "cornell" else max(8, H // 4)
+    rays, dt, y0 = sample(rows, threads)
+    rows1 = max(8, rows // 16)
+    rays1, dt1, y01 = sample(rows1, 1)
     s.close()
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "host_cores": os.cpu_count(),
             "sample": f"rows {y0}..{y0 + rows} of one {W}x{H} frame, {spp} spp, {depth} bounces, "
-                      f"{rays} rays in {dt:.2f} s", "fps_equivalent": round(rows / H / dt, 4) if rows else None}
+                      f"{rays} rays in {dt:.2f} s", "fps_equivalent": round(rows / H / dt, 4) if rows else None,
+            "single_thread": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                              "sample": f"rows {y01}..{y01 + rows1}, {rays1} rays in {dt1:.2f} s"}}
+
+
+class Farm:
+    """One workload on this rank: its band of the frame, double-buffered band images and (rank 0) assembled frames."""
+
+    def __init__(self, P, torch, dist, tilefarm, env, scene_name, W, H, spp, depth, args=None, preset=None):
+        self.P, self.torch, self.dist, self.tilefarm, self.env = P, torch, dist, tilefarm, env
+        rank, world, dev, rehearse = env["rank"], env["world"], env["dev"], env["rehearse"]
+        self.W, self.H, self.scene_name = W, H, scene_name
+        self.denoise = bool(args and args.denoise)
+        self.bloom = bool(args and args.bloom)
+        # N > 1: interleaved 8-row strips (every rank samples the whole frame: the showcase frame's worst BAND carries
+        # 1.6x the mean rays, three of eight being sky) unless --layout bands; the post chain on rank 0 gathers bands
+        self.strips = world > 1 and not (self.denoise or self.bloom) and (args is None or args.layout == "strips")
+        self.y0, self.rows = tilefarm.bands(H, world)[rank]  # horizontal bands; the last rank takes the remainder rows
+        if self.strips:
+            s = self.scene = build_scene(P, scene_name, W, H, 0, 0, dev, interleave=(rank, world))
+            self.rows = s.tile_rows
+        else:
+            s = self.scene = build_scene(P, scene_name, W, H, self.y0 if world > 1 else 0, self.rows if world > 1 else 0, dev)
+        s.setPerfSamplesPerPixel(spp)
+        s.setMaxBounceDepth(depth)
+        self.rebuild = bool(args and args.rebuild)
+        self.post_on_rank0 = world > 1 and (self.denoise or self.bloom)
+        if world == 1 and args is not None:
+            s.setDenoiserEnabled(args.denoise)
+            s.setBloomEnabled(args.bloom)
+            s.setResolutionScale(args.scale)
+            if preset:  # Scene::setPerformancePreset (scene.cuh:1833-1879): depth, scale, denoiser, bloom; ultra also 128 spp
+                s.setPerformancePreset(preset)
+        s.initBlueNoise()
+        s.uploadToGPU()
+        s.set_option("count_rays", 1)
+        for kv in (args.opt if args else []):
+            name, _, value = kv.partition("=")
+            s.set_option(name, int(value))
+        # render on torch's current stream so the RCCL gather is ordered after the frame without host syncs
+        self.stream = torch.cuda.current_stream()
+        s.set_stream(self.stream.cuda_stream)
+        # two band images + two assembled frames: frame i's gather (RCCL's own stream) overlaps frame
+        # i+1's render; a buffer is reused only after its gather has completed
+        trows = tilefarm.max_strip_rows(H, world) if self.strips else self.rows  # (strip images are padded to one size)
+        self.tiles = [torch.empty((trows, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.views = [None, None]
+        self.frames = self.parts = self.index = None
+        if world > 1 and rank == 0:
+            fdev = "cpu" if rehearse else "cuda"
+            self.frames = [torch.empty((H, W, 3), dtype=torch.uint8, device=fdev) for _ in range(2)]
+            self.views = [tilefarm.frame_views(f, H, world) for f in self.frames]
+            if self.strips:
+                self.parts = [[torch.empty((trows, W, 3), dtype=torch.uint8, device=fdev) for _ in range(world)] for _ in range(2)]
+                self.index = [torch.tensor(tilefarm.strip_frame_index(H, world, r), dtype=torch.long, device=fdev) for r in range(world)]
+        self.pending = [None, None]
+        # --denoise / --bloom with N > 1 (not the headline): the bands send HDR + G-buffers (32 B/px) instead of RGB8
+        # and rank 0 runs the post chain over the gathered frame in a second, full-frame context
+        # (tilefarm.gather_gbuffers, Scene.post_frame -> ptrt_post_frame)
+        self.presenter = self.gviews = self.gframe = self.gband = self.out_frame = None
+        if self.post_on_rank0:
+            kinds = dict(accum=P.BUF_ACCUM, normal=P.BUF_NORMAL, depth=P.BUF_DEPTH, object_id=P.BUF_OBJECT_ID)
+            self.gband = {k: torch.as_tensor(s.device_array(kind), device="cuda") for k, kind in kinds.items()}
+            if rank == 0:
+                pr = self.presenter = build_scene(P, scene_name, W, H, 0, 0, dev)
+                pr.setPerfSamplesPerPixel(spp)
+                pr.setMaxBounceDepth(depth)
+                pr.setDenoiserEnabled(self.denoise)
+                pr.setBloomEnabled(self.bloom)
+                pr.initBlueNoise()
+                pr.uploadToGPU()
+                pr.set_stream(self.stream.cuda_stream)
+                d = "cpu" if rehearse else "cuda"
+                self.gframe = {k: torch.empty((H * W, c), dtype=getattr(torch, dt), device=d) for k, c, dt in tilefarm.GBUFFER_KINDS}
+                self.gviews = tilefarm.gbuffer_views(self.gframe, H, world)
+                self.out_frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        # config 5 ("fluid"): every step first moves the water surface (new vertex positions already in
+        # HBM), refits the BVH on the GPU, then traces: the refit+trace pipeline, no host sync inside
+        self.water = None
+        if scene_name == "fluid":
+            import numpy as np
+            self.water = [torch.from_numpy(np.ascontiguousarray(P.scenes.water_vertices(256, t / 60.0))).cuda()
+                          for t in range(8)]
+        self.counter = [0, 0]
+
+    def step(self):
+        s, env, tf = self.scene, self.env, self.tilefarm
+        rank, world, rehearse = env["rank"], env["world"], env["rehearse"]
+        if self.water is not None:
+            move = s.rebuildFromDevice if self.rebuild else s.refitFromDevice
+            move(s.water_mesh, self.water[self.counter[0] % len(self.water)].data_ptr())
+            self.counter[0] += 1
+        b = self.counter[1] & 1
+        self.counter[1] += 1
+        self._retire(b)
+        s.render_to_device(self.tiles[b].data_ptr())
+        if self.post_on_rank0:
+            src = {k: (t.cpu() if rehearse else t) for k, t in self.gband.items()}
+            tf.gather_gbuffers(self.dist, src, self.gviews, rank, world, self.H)
+            if rank == 0:
+                fr = {k: (t.cuda() if rehearse else t) for k, t in self.gframe.items()}
+                self.presenter.post_frame(fr["accum"].data_ptr(), fr["normal"].data_ptr(), fr["depth"].data_ptr(),
+                                          fr["object_id"].data_ptr(), self.out_frame.data_ptr())
+            return
+        if self.strips:
+            parts = self.parts[b] if rank == 0 else None
+            if rehearse:
+                tf.gather_strips(self.dist, self.tiles[b].cpu(), self.frames[b] if rank == 0 else None, parts, self.index,
+                                 rank, world)
+            else:
+                self.pending[b] = tf.gather_strips(self.dist, self.tiles[b], None, parts, self.index, rank, world, async_op=True)
+        elif rehearse:
+            tf.gather_bands(self.dist, self.tiles[b].cpu(), self.views[b], rank, world, self.H)
+        else:
+            self.pending[b] = tf.gather_bands(self.dist, self.tiles[b], self.views[b], rank, world, self.H, async_op=True)
+
+    def _retire(self, b):
+        """Completes frame buffer b's gather (and, for strips, scatters the parts into the frame on rank 0)."""
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+            if self.strips and self.env["rank"] == 0:
+                self.tilefarm.scatter_strips(self.frames[b], self.parts[b], self.index)
+
+    def fence(self):
+        for b in (0, 1):
+            self._retire(b)
+        if self.env["world"] > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, steps, warmup):
+        """W untimed frames, then exactly `steps` frames between barrier + synchronize brackets; the MAX over ranks."""
+        torch, env = self.torch, self.env
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        self.scene.stats()  # reset counters
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        st = self.scene.stats()
+        rays = float(st["extension_rays"] + st["shadow_rays"])
+        kms = self.scene.kernel_ms_history(steps)
+        kernel_ms = float(kms.mean()) if len(kms) else float("nan")
+        if env["world"] > 1:
+            t = torch.tensor([dt, rays, kernel_ms], dtype=torch.float64, device="cpu" if env["rehearse"] else "cuda")
+            tmax, tsum = t.clone(), t.clone()
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            self.dist.all_reduce(tsum, op=self.dist.ReduceOp.SUM)
+            dt, rays, kernel_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
+        return dict(dt=dt, rays=rays, kernel_ms=kernel_ms, steps=steps)
+
+    def close(self):
+        self.scene.close()
+        if self.presenter is not None:
+            self.presenter.close()
+        self.tiles = self.views = None
+
+
+def roofline_block(config_name, kernel_ms, pixels):
+    """HBM entry per the bench contract (algorithmic bytes / kernel time / peak) plus the bound that binds this path:
+    VALU issue.  Instruction counts, lane occupancy and measured HBM traffic come from the committed profile summary
+    (profiles/summarize.py -> profiles/r02_roofline_inputs.json), the kernel time from this run's HIP events."""
+    algo_bytes = ALGO_BYTES_PER_PIXEL * pixels
+    ok = kernel_ms == kernel_ms and kernel_ms > 0
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if ok else None
+    prof = {}
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_inputs.json"))).get(config_name, {})
+    except Exception:
+        prof = {}
+    valu = prof.get("valu_wave_instructions_per_launch")
+    block = {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6),
+             "traffic": prof.get("hbm_bytes_per_launch"), "kernel_ms": round(kernel_ms, 4) if ok else None,
+             "algorithmic_bytes_per_launch": algo_bytes,
+             "binding": "VALU issue + memory latency under divergence (SURVEY 8(d)); the HBM entry is the contract's, not the limit",
+             "valu_issue_frac": round(valu * VALU_CYCLES / (kernel_ms * 1e-3 * SIMDS * CLOCK_HZ), 4) if (valu and ok) else None,
+             "valu_wave_instructions_per_launch": valu, "lane_busy": prof.get("lane_busy"),
+             "profile": prof.get("source")}
+    return block
 
 
 def main():
@@ -70,12 +284,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="cornell")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=4)
-    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--config", default="cornell1080", choices=sorted(CONFIGS))
+    ap.add_argument("--scene", default=None, help="override the config's scene (also: many, matrix)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--preset", default=None, choices=["fast", "performance", "balanced", "quality", "ultra"],
+                    help="Scene::setPerformancePreset on the measured scene (N=1 only; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the extra configs[3] measurement of a default run")
     ap.add_argument("--denoise", action="store_true",
                     help="also run motion vectors + the spatiotemporal denoiser each frame (N=1 only; not the headline)")
     ap.add_argument("--bloom", action="store_true", help="also run the bloom chain (N=1 only; not the headline)")
@@ -86,9 +304,19 @@ def main():
                          "host, SLOTS-deep ring) and report its PCIe-inclusive ms/frame as config.present_ms_per_frame")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="ptrt_set_option for A/B experiments (e.g. pair_trace=0); not for the headline")
+    ap.add_argument("--layout", default="strips", choices=["strips", "bands"],
+                    help="N > 1: interleaved 8-row strips per rank (default: balanced) or contiguous bands")
+    ap.add_argument("--farm", type=int, default=0, metavar="PARTS",
+                    help="N=1 only, not the headline: also time the single-process C++ TileFarm (ptrt_farm_*) with PARTS "
+                         "parts over the visible devices and report config.farm_ms_per_frame")
     ap.add_argument("--rebuild", action="store_true",
                     help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("scene", "width", "height", "spp", "depth"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    headline = cfg == CONFIGS["cornell1080"] and not (args.denoise or args.bloom or args.preset or args.opt or args.scale != 1.0)
 
     import torch
     import ptrt_amd as P
@@ -112,172 +340,97 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     from ptrt_amd import tilefarm
-    W, H = args.width, args.height
-    y0, rows = tilefarm.bands(H, world)[rank]  # horizontal bands; the last rank takes the remainder rows
-    scene = build_scene(P, args.scene, W, H, y0 if world > 1 else 0, rows if world > 1 else 0, dev_index)
-    scene.setPerfSamplesPerPixel(args.spp)
-    scene.setMaxBounceDepth(args.depth)
-    post_on_rank0 = world > 1 and (args.denoise or args.bloom)
-    if world == 1:
-        scene.setDenoiserEnabled(args.denoise)
-        scene.setBloomEnabled(args.bloom)
-        scene.setResolutionScale(args.scale)
-    scene.initBlueNoise()
-    scene.uploadToGPU()
-    scene.set_option("count_rays", 1)
-    for kv in args.opt:
-        name, _, value = kv.partition("=")
-        scene.set_option(name, int(value))
-    # render on torch's current stream so the RCCL gather is ordered after the frame without host syncs
-    stream = torch.cuda.current_stream()
-    scene.set_stream(stream.cuda_stream)
+    env = dict(rank=rank, world=world, dev=dev_index, rehearse=rehearse)
 
-    # two band images + two assembled frames: frame i's gather (RCCL's own stream) overlaps frame
-    # i+1's render; a buffer is reused only after its gather has completed
-    tiles = [torch.empty((rows, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    views = [None, None]
-    if world > 1 and rank == 0:
-        frames = [torch.empty((H, W, 3), dtype=torch.uint8, device="cpu" if rehearse else "cuda") for _ in range(2)]
-        views = [tilefarm.frame_views(f, H, world) for f in frames]
-    pending = [None, None]
+    W, H = cfg["width"], cfg["height"]
+    farm = Farm(P, torch, dist, tilefarm, env, cfg["scene"], W, H, cfg["spp"], cfg["depth"], args=args, preset=args.preset)
+    m = farm.measure(args.steps, args.warmup)
+    settings = farm.scene.settings()
+    present = None
+    if args.present > 0 and world == 1:
+        farm.scene.set_stream(0)  # the viewer loop runs on the context's own stream
+        farm.scene.view_run(args.warmup + 2, slots=args.present, keep=False)
+        _, present = farm.scene.view_run(args.steps, slots=args.present, keep=False)
+    rows0 = farm.rows
+    post_on_rank0 = farm.post_on_rank0
+    layout = "strips" if farm.strips else "bands"
+    farm.close()
+    farm_ms = farm_transport = None
+    if args.farm > 0 and world == 1:  # the C++ farm below the C ABI: one process, its parts cycled over the visible devices
+        ndev = torch.cuda.device_count()
+        tf_ = P.TileFarm(W, H, [i % ndev for i in range(args.farm)], strips=(args.layout == "strips"))
+        for sc in tf_.scenes:
+            getattr(P.scenes, {"matrix": "material_matrix"}.get(cfg["scene"], cfg["scene"]))(sc)
+            sc.setPerfSamplesPerPixel(cfg["spp"])
+            sc.setMaxBounceDepth(cfg["depth"])
+            sc.setDenoiserEnabled(False)
+            sc.setBloomEnabled(False)
+            sc.initBlueNoise()
+            sc.uploadToGPU()
+        target = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
+        for _ in range(args.warmup):
+            tf_.render_to_device(target.data_ptr())
+        tf_.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tf_.render_to_device(target.data_ptr())
+        tf_.sync()
+        for d in range(ndev):
+            torch.cuda.synchronize(d)
+        farm_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        farm_transport = tf_.transport
+        tf_.close()
 
-    # --denoise / --bloom with N > 1 (not the headline): the bands send HDR + G-buffers (32 B/px) instead of RGB8 and
-    # rank 0 runs the post chain over the gathered frame in a second, full-frame context (tilefarm.gather_gbuffers,
-    # Scene.post_frame -> ptrt_post_frame)
-    presenter = gviews = gframe = gband = out_frame = None
-    if post_on_rank0:
-        kinds = dict(accum=P.BUF_ACCUM, normal=P.BUF_NORMAL, depth=P.BUF_DEPTH, object_id=P.BUF_OBJECT_ID)
-        gband = {k: torch.as_tensor(scene.device_array(kind), device="cuda") for k, kind in kinds.items()}
-        if rehearse:
-            gband_host = None
-        if rank == 0:
-            presenter = build_scene(P, args.scene, W, H, 0, 0, dev_index)
-            presenter.setPerfSamplesPerPixel(args.spp)
-            presenter.setMaxBounceDepth(args.depth)
-            presenter.setDenoiserEnabled(args.denoise)
-            presenter.setBloomEnabled(args.bloom)
-            presenter.initBlueNoise()
-            presenter.uploadToGPU()
-            presenter.set_stream(stream.cuda_stream)
-            dev = "cpu" if rehearse else "cuda"
-            gframe = {k: torch.empty((H * W, c), dtype=getattr(torch, dt), device=dev) for k, c, dt in tilefarm.GBUFFER_KINDS}
-            gviews = tilefarm.gbuffer_views(gframe, H, world)
-            out_frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    # configs[3] (showcase 3840x2160, 8 spp) over the same ranks, a few frames: the curve BASELINE asks for
+    c3 = None
+    if headline and not args.no_configs3:
+        c = CONFIGS["showcase4k8"]
+        n3 = max(2, min(args.steps, 6))
+        f3 = Farm(P, torch, dist, tilefarm, env, c["scene"], c["width"], c["height"], c["spp"], c["depth"])
+        m3 = f3.measure(n3, 1)
+        f3.close()
+        c3 = {"workload": f"showcase {c['width']}x{c['height']} {c['spp']}spp {c['depth']}-bounce, {world} band(s)",
+              "metric": "Mrays/s", "value": round(m3["rays"] / m3["dt"] / 1e6, 2), "n_gpus": world, "steps": n3, "warmup": 1,
+              "ms_per_step": round(m3["dt"] / n3 * 1e3, 4), "fps": round(n3 / m3["dt"], 3), "scaling": "strong",
+              "rays_per_frame": round(m3["rays"] / n3), "kernel_ms_max_over_ranks": round(m3["kernel_ms"], 4)}
 
-    # config 5 ("fluid"): every step first moves the water surface (new vertex positions already in
-    # HBM), refits the BVH on the GPU, then traces: the refit+trace pipeline, no host sync inside
-    water = None
-    if args.scene == "fluid":
-        import numpy as np
-        water = [torch.from_numpy(np.ascontiguousarray(P.scenes.water_vertices(256, t / 60.0))).cuda()
-                 for t in range(8)]
-    counter = [0, 0]
-
-    def step():
-        if water is not None:
-            move = scene.rebuildFromDevice if args.rebuild else scene.refitFromDevice
-            move(scene.water_mesh, water[counter[0] % len(water)].data_ptr())
-            counter[0] += 1
-        b = counter[1] & 1
-        counter[1] += 1
-        if pending[b] is not None:
-            pending[b].wait()
-        scene.render_to_device(tiles[b].data_ptr())
-        if post_on_rank0:
-            src = {k: (t.cpu() if rehearse else t) for k, t in gband.items()}
-            tilefarm.gather_gbuffers(dist, src, gviews, rank, world, H)
-            if rank == 0:
-                fr = {k: (t.cuda() if rehearse else t) for k, t in gframe.items()}
-                presenter.post_frame(fr["accum"].data_ptr(), fr["normal"].data_ptr(), fr["depth"].data_ptr(),
-                                     fr["object_id"].data_ptr(), out_frame.data_ptr())
-            return
-        if rehearse:
-            tilefarm.gather_bands(dist, tiles[b].cpu(), views[b], rank, world, H)
-        else:
-            pending[b] = tilefarm.gather_bands(dist, tiles[b], views[b], rank, world, H, async_op=True)
-
-    def fence():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    scene.stats()  # reset counters
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-
-    st = scene.stats()
-    rays = float(st["extension_rays"] + st["shadow_rays"])
-    kms = scene.kernel_ms_history(args.steps)
-    kernel_ms = float(kms.mean()) if len(kms) else float("nan")
-    if world > 1:
-        t = torch.tensor([dt, rays, kernel_ms], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0])
-        rays = float(tsum[1])
-        kernel_ms = float(tmax[2])
     if rank != 0:
         dist.destroy_process_group()
         return
 
+    dt, rays, kernel_ms = m["dt"], m["rays"], m["kernel_ms"]
     ms_per_step = dt / args.steps * 1e3
-    mrays = rays / dt / 1e6
-    fps = args.steps / dt
-    tile_pixels = W * rows  # rank 0's launch
-    algo_bytes = ALGO_BYTES_PER_PIXEL * tile_pixels
-    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms and kernel_ms > 0 else None
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if world == 1 and os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"{args.scene}_{W}x{H}_{args.spp}spp_{args.depth}b"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    spp_used, depth_used = settings["spp"], settings["depth"]
     out = {
-        "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
+        "metric": "Mrays/s", "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         **({"rehearsal": "gloo + host staging on one GPU: NOT a measurement"} if rehearse else {}),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "fps": round(fps, 2),
+        "fps": round(args.steps / dt, 2),
         "rays_per_frame": round(rays / args.steps),
-        "config": {"workload": f"{args.scene} {W}x{H} {args.spp}spp {args.depth}-bounce"
+        "rays_note": "extension + shadow rays of the reference path (== the oracle's counts); a light sample whose value "
+                     "is exactly zero is counted but its shadow ray is not walked (DESIGN.md 3.1)",
+        "config": {"workload": f"{cfg['scene']} {W}x{H} {spp_used}spp {depth_used}-bounce"
+                               + (f" preset {args.preset}" if args.preset else "")
                                + (" +denoise" if args.denoise else "") + (" +bloom" if args.bloom else "")
                                + (f" scale{args.scale}" if args.scale != 1.0 else "")
-                               + (" +gpu-rebuild" if args.rebuild else ""), "scene": args.scene,
-                   "width": W, "height": H, "spp": args.spp, "max_depth": args.depth,
-                   "parallelism": (f"tile{world}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
+                               + (" +gpu-rebuild" if args.rebuild else ""), "name": args.config, "scene": cfg["scene"],
+                   "width": W, "height": H, "spp": spp_used, "max_depth": depth_used,
+                   "parallelism": (f"tile{world}-{layout}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
                    "kernel": "path_trace_kernel (megakernel, fused tonemap)"},
-        "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                     "algorithmic_bytes_per_launch": algo_bytes,
-                     "note": "path is VALU/latency bound, not HBM bound (SURVEY 8(d)); see DESIGN.md"},
+        "roofline": roofline_block(args.config if world == 1 else None, kernel_ms, W * rows0),
     }
-    if args.present > 0 and world == 1:
-        scene.set_stream(0)  # the viewer loop runs on the context's own stream
-        scene.view_run(args.warmup + 2, slots=args.present, keep=False)
-        _, pms = scene.view_run(args.steps, slots=args.present, keep=False)
-        out["config"]["present_ms_per_frame"] = round(pms, 4)
+    if c3 is not None:
+        out["configs3"] = c3
+    if farm_ms is not None:
+        out["config"]["farm_ms_per_frame"] = round(farm_ms, 4)
+        out["config"]["farm"] = f"{args.farm} parts, {args.layout}, one process, transport {farm_transport}"
+    if present is not None:
+        out["config"]["present_ms_per_frame"] = round(present, 4)
         out["config"]["present_slots"] = args.present
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(P, args.scene, W, H, args.spp, args.depth, 0,
+        out["cpu_baseline"] = cpu_baseline(P, cfg["scene"], W, H, spp_used, depth_used, 0,
                                            min(16, len(os.sched_getaffinity(0))))
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -190,6 +190,14 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
  * slot are tolerated the way the reference tolerates double cudaFree. */
 void ptrt_destroy(ptrt_ctx *ctx);
 
+/* The same for a context that owns every `period`-th 8-row strip of the frame, starting with strip `phase`
+ * (strip t = rows 8t .. 8t+7): the tile farm's other way of cutting a frame (SURVEY 8(e) "interleaved strips ... to
+ * balance sky vs geometry").  Contiguous bands of the showcase frame carry 1.6x the mean number of rays in the worst
+ * band (three of eight bands are sky); interleaved, every context samples the whole frame.  The context's buffers
+ * hold its strips one after the other (top-down; the RGB8 image bottom-up within them, like a band's);
+ * period == 1 is the whole frame.  ABI 4. */
+int ptrt_create_interleaved(int full_w, int full_h, int phase, int period, int device, ptrt_ctx **out);
+
 const char *ptrt_last_error(const ptrt_ctx *ctx); /* never NULL */
 int ptrt_abi_version(void);
 
@@ -405,6 +413,27 @@ int ptrt_get_stats(ptrt_ctx *ctx, ptrt_stats *out);
  * render size, or when neither stage is enabled. */
 int ptrt_post_frame(ptrt_ctx *ctx, const float *accum, const float *normal, const float *depth,
                     const int32_t *object_id, void *out_rgb8, int out_is_device);
+
+/* ---- the tile farm below the C ABI: one process, the GPUs of one node --------------------------------
+ * The reference has no multi-GPU code; a C++ application built on the Scene mirror farms a frame by holding one
+ * band / strip context per GPU (ptrt_create / ptrt_create_interleaved with the device of each) and handing them
+ * to a farm, which gathers their RGB8 images onto the device of the FIRST context -- the presenting device, whose
+ * viewer maps the frame (rtgl::map_pbo_device_ptr).  Contexts on the presenting device are copied device-to-device;
+ * contexts on other devices send with ncclSend / ncclRecv over RCCL (xGMI), one grouped call per frame; strips are
+ * scattered to their places.  No host synchronisation inside a frame (out_is_device != 0); a context's next render
+ * waits on its own stream until its image has been taken.  The contexts stay the caller's (uploads, options, destroy
+ * them AFTER the farm); they must tile the frame exactly once, else PTRT_E_INVALID.
+ *   ptrt_farm_render  = ptrt_render(ctx, frame, spp, depth, NULL, 0) on every context + ptrt_farm_gather
+ *   ptrt_farm_gather  = gather of the images the contexts hold (for callers that render through the Scene mirror)
+ *   ptrt_farm_transport: "device-copy" (all contexts on one device) or "rccl".  Errors: ptrt_last_error(NULL). */
+typedef struct ptrt_farm ptrt_farm;
+int ptrt_farm_create(ptrt_ctx *const *contexts, int n_contexts, ptrt_farm **out);
+int ptrt_farm_bands(const ptrt_farm *farm);
+const char *ptrt_farm_transport(const ptrt_farm *farm);
+int ptrt_farm_render(ptrt_farm *farm, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device);
+int ptrt_farm_gather(ptrt_farm *farm, void *out_rgb8, int out_is_device);
+int ptrt_farm_sync(ptrt_farm *farm);
+void ptrt_farm_destroy(ptrt_farm *farm);
 
 /* tuning / diagnostics knobs, by name; unknown names return PTRT_E_INVALID.  None changes a bit of
  * any output (tests force every value and compare with the oracle):

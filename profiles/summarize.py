@@ -30,3 +30,49 @@ json.dump(out, open(f"profiles/{rnd}_{tag}_pmc.json", "w"), indent=1)
 for k in sorted(c):
     print(f"{k:28s} {c[k]['mean_per_launch']:.4g}")
 print(out.get("dispatch"))
+
+# ---- inputs of bench.py's `roofline` block (profiles/<round>_roofline_inputs.json), keyed by bench --config name:
+#   python profiles/summarize.py <tag> <round> <config>      e.g.  summarize.py cornell1080 r02 cornell1080
+# VALU wave-instructions per launch (SQ_INSTS_VALU), HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (KB) with the
+# gfx950 correction of MI355X_MICROARCH.md "HBM" (FETCH_SIZE tallies 128-B read requests at 64 B: doubled; other
+# access widths are uncalibrated there, so the uncorrected sum is kept beside it), and the lane occupancy of the
+# traversal loops from the instrumented build's report (profiles/<round>_lane_occupancy.txt, section "### <config>").
+if len(sys.argv) > 3:
+    import re
+    cfg = sys.argv[3]
+    path = f"profiles/{rnd}_roofline_inputs.json"
+    try:
+        allcfg = json.load(open(path))
+    except Exception:
+        allcfg = {}
+    entry = {"source": f"profiles/{rnd}_{tag}_pmc.json"}
+    if "SQ_INSTS_VALU" in c:
+        entry["valu_wave_instructions_per_launch"] = round(c["SQ_INSTS_VALU"]["mean_per_launch"])
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        f, w = c["FETCH_SIZE"]["mean_per_launch"] * 1024, c["WRITE_SIZE"]["mean_per_launch"] * 1024
+        entry["hbm_bytes_per_launch"] = round(2 * f + w)
+        entry["hbm_bytes_per_launch_uncorrected"] = round(f + w)
+    occ = f"profiles/{rnd}_lane_occupancy.txt"
+    if os.path.exists(occ):
+        sect = re.split(r"^### ", open(occ).read(), flags=re.M)
+        for s_ in sect:
+            if s_.split("\n", 1)[0].strip() == cfg:
+                lb = {}
+                kind = None
+                for line in s_.split("\n"):
+                    m = re.match(r"(closest|any-hit):", line)
+                    if m:
+                        kind = m.group(1)
+                    m = re.search(r"node steps: .*lanes busy ([0-9.]+) %", line)
+                    if m and kind:
+                        lb[f"{kind}_node_loop"] = float(m.group(1)) / 100
+                    m = re.search(r"triangle loop: .*lanes busy ([0-9.]+) %", line)
+                    if m and kind:
+                        lb[f"{kind}_triangle_loop"] = float(m.group(1)) / 100
+                    m = re.search(r"persistent loop: .*live lanes ([0-9.]+) %", line)
+                    if m:
+                        lb["live_lanes"] = float(m.group(1)) / 100
+                entry["lane_busy"] = lb
+    allcfg[cfg] = entry
+    json.dump(allcfg, open(path, "w"), indent=1, sort_keys=True)
+    print("roofline inputs:", cfg, entry)

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
                 ring_n -= n_take;
             }
             if (need_regen) { // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
-                const int y = K.y0 + yl;
+                const int y = global_row(yl, K.y0, K.il_period, K.il_phase);
                 float tjx, tjy, bnx, bny;
                 taa_jitter(K.frame_count + s, tjx, tjy);
                 blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);

@@ -87,6 +87,7 @@ struct KParams {
     int env_w, env_h;
     int width, height; // full frame
     int y0, rows;      // tile
+    int il_period, il_phase; // > 1: the context owns the 8-row strips `phase, phase + period, ...` of the frame (global_row)
     int tiles_x;
     int spp, max_depth, frame_count;
     // buffers (tile-sized)
@@ -97,6 +98,11 @@ struct KParams {
     unsigned char *rgb8;
     unsigned long long *counters; // {extension, shadow, paths} or nullptr
 };
+
+// frame row of a context's local row: contiguous rows from y0, or every il_period-th 8-row strip from strip il_phase
+PT_DEV int global_row(int yl, int y0, int il_period, int il_phase) {
+    return il_period > 1 ? ((((yl >> 3) * il_period + il_phase) << 3) | (yl & 7)) : y0 + yl;
+}
 
 constexpr int MESH_REC_F4 = 12;
 constexpr int TLAS_HEAD_F4 = 5; // head + the three rows of the inverse matrix: what the root-box test of an instance needs
@@ -642,14 +648,16 @@ PT_DEV LightRec load_light(const float4 *__restrict__ L, int i) {
 // 2^67 draws.  jump[k] = (step^(2^67))^(2^k) as 160 columns x 5 words; a lane applies
 // the matrices selected by the bits of its pixel index.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void xorwow_init_kernel(uint32_t *rng, int width, int rows, int y0, uint32_t d0,
-                                                          uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3,
-                                                          uint32_t s4, const uint32_t *__restrict__ jump, int n_jump) {
+__global__ __launch_bounds__(256) void xorwow_init_kernel(uint32_t *rng, int width, int rows, int y0, int il_period,
+                                                          int il_phase, uint32_t d0, uint32_t s0, uint32_t s1, uint32_t s2,
+                                                          uint32_t s3, uint32_t s4, const uint32_t *__restrict__ jump,
+                                                          int n_jump) {
     const size_t npix = (size_t)rows * width;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix)
         return;
-    unsigned long long n = (unsigned long long)y0 * (unsigned long long)width + i; // global y*W+x
+    const int yl = (int)(i / (size_t)width), x = (int)(i % (size_t)width);
+    unsigned long long n = (unsigned long long)global_row(yl, y0, il_period, il_phase) * (unsigned long long)width + x; // global y*W+x
     uint32_t v[5] = {s0, s1, s2, s3, s4};
     for (int k = 0; k < n_jump && n; ++k, n >>= 1) {
         if (!(n & 1ull))

@@ -280,7 +280,7 @@ template <bool FULL> __global__ __launch_bounds__(256) void wf_shade_kernel(cons
         const int x = tx * 8 + (l & 7);
         const int yl = ty * 8 + (l >> 3);
         const bool inside = (x < K.width) && (yl < K.rows);
-        const int y = K.y0 + yl;
+        const int y = global_row(yl, K.y0, K.il_period, K.il_phase);
         const size_t npix = K.rng_plane;
         const size_t idx = (size_t)yl * K.width + x;
         uint32_t st = first ? 0u : W.st[q];

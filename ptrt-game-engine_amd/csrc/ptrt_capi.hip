@@ -42,6 +42,7 @@ struct ptrt_ctx {
     std::vector<hipEvent_t> ev_ring; // 2 * EV_RING events: start/stop per launch
     unsigned long long launches = 0;
     int W = 0, H = 0, y0 = 0, rows = 0;
+    int il_period = 1, il_phase = 0; // > 1: rows = the 8-row strips il_phase, il_phase + il_period, ... of the frame
     size_t npix = 0;
     std::string err;
 
@@ -523,6 +524,8 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.width = c->rw;
     K.height = c->rh;
     K.y0 = c->y0;
+    K.il_period = c->il_period;
+    K.il_phase = c->il_phase;
     K.rows = scaled ? c->rh : c->rows;
     K.tiles_x = (c->rw + 7) / 8;
     K.rng = c->d_rng;
@@ -958,6 +961,10 @@ const char *ptrt_last_error(const ptrt_ctx *ctx) {
     return g_last_error.c_str();
 }
 
+namespace {
+int create_ctx(int full_w, int full_h, int tile_y0, int tile_rows, int il_period, int il_phase, int device, ptrt_ctx **out);
+}
+
 int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, ptrt_ctx **out) {
     if (!out)
         return fail(nullptr, PTRT_E_INVALID, "ptrt_create: out is NULL");
@@ -971,6 +978,30 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
     if (tile_y0 < 0 || tile_y0 + tile_rows > full_h)
         return fail(nullptr, PTRT_E_INVALID, "ptrt_create: tile rows [%d,%d) outside 0..%d", tile_y0,
                     tile_y0 + tile_rows, full_h);
+    return create_ctx(full_w, full_h, tile_y0, tile_rows, 1, 0, device, out);
+}
+
+int ptrt_create_interleaved(int full_w, int full_h, int phase, int period, int device, ptrt_ctx **out) {
+    if (!out)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_create_interleaved: out is NULL");
+    *out = nullptr;
+    if (full_w <= 0 || full_h <= 0)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_create_interleaved: bad frame size %dx%d", full_w, full_h);
+    const int strips = (full_h + 7) / 8;
+    if (period < 1 || phase < 0 || phase >= period || phase >= strips)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_create_interleaved: strip %d of every %d (the frame has %d strips of 8 rows)",
+                    phase, period, strips);
+    if (period == 1)
+        return create_ctx(full_w, full_h, 0, full_h, 1, 0, device, out);
+    // rows of the strips phase, phase + period, ...; only the frame's last strip can be short, and it is the owner's last
+    int rows = 0;
+    for (int t = phase; t < strips; t += period)
+        rows += (t * 8 + 8 <= full_h) ? 8 : full_h - t * 8;
+    return create_ctx(full_w, full_h, phase * 8, rows, period, phase, device, out);
+}
+
+namespace {
+int create_ctx(int full_w, int full_h, int tile_y0, int tile_rows, int il_period, int il_phase, int device, ptrt_ctx **out) {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -984,6 +1015,8 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
     c->H = full_h;
     c->y0 = tile_y0;
     c->rows = tile_rows;
+    c->il_period = il_period;
+    c->il_phase = il_phase;
     c->npix = (size_t)full_w * tile_rows;
     c->rw = full_w;
     c->rh = full_h;
@@ -1031,6 +1064,7 @@ int ptrt_create(int full_w, int full_h, int tile_y0, int tile_rows, int device, 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PTRT_OK;
 }
+} // namespace
 
 void ptrt_destroy(ptrt_ctx *c) {
     {
@@ -1091,7 +1125,7 @@ int ptrt_reset_rng(ptrt_ctx *c, unsigned long long seed) {
     if (int rc = set_device(c))
         return rc;
     // bits needed for the largest global pixel index of this tile
-    const unsigned long long last = (unsigned long long)(c->y0 + c->rows) * (unsigned long long)c->W;
+    const unsigned long long last = (unsigned long long)(c->il_period > 1 ? c->H : c->y0 + c->rows) * (unsigned long long)c->W;
     int bits = 1;
     while ((last >> bits) != 0)
         ++bits;
@@ -1114,7 +1148,7 @@ int ptrt_reset_rng(ptrt_ctx *c, unsigned long long seed) {
                    v4 = 5783321u + t0;
     const int grid = (int)((c->npix + 255) / 256);
     hipLaunchKernelGGL(pt::xorwow_init_kernel, dim3(grid), dim3(256), 0, c->stream, c->d_rng, c->W, c->rows, c->y0,
-                       d0, v0, v1, v2, v3, v4, c->d_jump, c->n_jump);
+                       c->il_period, c->il_phase, d0, v0, v1, v2, v3, v4, c->d_jump, c->n_jump);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream)); // the reference synchronises here too (scene.cuh:455)
     c->rng_ready = true;
@@ -2369,3 +2403,5 @@ int ptrt_debug_detmath(ptrt_ctx *c, int op, const float *x, const float *y, int 
 }
 
 } // extern "C"
+
+#include "ptrt_farm.hip.h"

@@ -1,0 +1,318 @@
+// ptrt_farm.hip.h -- the tile farm below the C ABI (ptrt_farm_*, include/ptrt.h): band / strip contexts of ONE process
+// on the GPUs of one node, their RGB8 images gathered onto the presenting device.  Included by ptrt_capi.hip (it
+// reads the contexts' tile geometry, device and stream).
+//
+// Frames are cut either into contiguous bands (ptrt_create) or into interleaved 8-row strips
+// (ptrt_create_interleaved); the farm takes any set of contexts that tiles the frame exactly once.  A frame:
+//   1. every context renders its rows into its own RGB8 buffer (ptrt_render with a NULL target: asynchronous, on
+//      the context's stream, on its device);
+//   2. contexts on the PRESENTING device (that of the first context) are copied device-to-device behind an event;
+//      contexts on other devices send their image with ncclSend on their own stream, the presenting device posts the
+//      matching ncclRecv on the farm's stream -- one grouped call per frame (RCCL over xGMI: point-to-point links into
+//      the presenter, 0.78 MB per band at 1080p / 8 GPUs, 3.1 MB at 4K);
+//   3. bands land in the frame where they belong; strips are scattered with one strided copy per context.
+// No host synchronisation inside a frame; the next render of a context waits (on its stream) until its image has
+// been taken.  RCCL is loaded on first use (dlopen), so the library has no link-time dependency on it and a
+// single-GPU box never touches it.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct ptrt_farm {
+    std::vector<ptrt_ctx *> band;
+    std::vector<hipEvent_t> rendered, taken; // per context: image complete / image copied out
+    std::vector<unsigned char *> staging;    // per context on another device: where its image is received
+    std::vector<int> comm_rank;              // per context: rank of its device in `comms` (-1: presenting device)
+    std::vector<ncclComm_t> comms;           // one per distinct device, [0] = presenting device
+    std::vector<int> comm_dev;
+    int W = 0, H = 0, device = 0;
+    hipStream_t stream = nullptr;            // presenting device: receives, copies
+    unsigned char *d_frame = nullptr;        // assembled frame when the caller's target is host memory
+    bool primed = false;
+    std::string transport = "device-copy";
+};
+
+namespace {
+
+std::mutex g_farm_mutex;
+std::set<ptrt_farm *> g_farms;
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib)
+                break;
+        }
+        if (!r.lib)
+            return;
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+        r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+        r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
+    });
+    return r;
+}
+
+bool farm_live(ptrt_farm *f) {
+    std::lock_guard<std::mutex> lock(g_farm_mutex);
+    return f && g_farms.count(f);
+}
+
+void farm_free(ptrt_farm *f) {
+    for (size_t i = 0; i < f->comms.size(); ++i)
+        if (f->comms[i]) {
+            (void)hipSetDevice(f->comm_dev[i]);
+            (void)rccl().CommDestroy(f->comms[i]);
+        }
+    (void)hipSetDevice(f->device);
+    if (f->stream) {
+        (void)hipStreamSynchronize(f->stream);
+        (void)hipStreamDestroy(f->stream);
+    }
+    for (unsigned char *p : f->staging)
+        if (p)
+            (void)hipFree(p);
+    if (f->d_frame)
+        (void)hipFree(f->d_frame);
+    for (size_t i = 0; i < f->band.size(); ++i) {
+        if (ctx_live(f->band[i]))
+            (void)hipSetDevice(f->band[i]->device);
+        if (i < f->rendered.size() && f->rendered[i])
+            (void)hipEventDestroy(f->rendered[i]);
+        if (i < f->taken.size() && f->taken[i])
+            (void)hipEventDestroy(f->taken[i]);
+    }
+    delete f;
+}
+
+// Copies one context's image (device pointer on the presenting device) to its place in the frame, on `st`.
+// A band is one block of rows; the strips of an interleaved context lie `period` strips apart.  Both images are
+// bottom-up: frame byte row of view row y is H-1-y, a context's byte row of its local row yl is rows-1-yl.
+hipError_t place_image(const ptrt_ctx *c, const unsigned char *src, unsigned char *frame, hipStream_t st) {
+    const size_t row = (size_t)c->W * 3;
+    if (c->il_period <= 1)
+        return hipMemcpyAsync(frame + (size_t)(c->H - (c->y0 + c->rows)) * row, src, (size_t)c->rows * row, hipMemcpyDeviceToDevice, st);
+    const int strips = (c->H + 7) / 8, last_rows = c->H - (strips - 1) * 8; // the frame's last strip may be short
+    int n_local = 0;
+    for (int t = c->il_phase; t < strips; t += c->il_period)
+        ++n_local;
+    const int t_last = c->il_phase + (n_local - 1) * c->il_period; // the context's last strip (top-down) = first in its image
+    const bool owns_short = (t_last == strips - 1) && last_rows != 8;
+    const unsigned char *s = src;
+    int n_full = n_local;
+    if (owns_short) { // frame rows [0, last_rows)
+        const hipError_t e = hipMemcpyAsync(frame, s, (size_t)last_rows * row, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess)
+            return e;
+        s += (size_t)last_rows * row;
+        --n_full;
+    }
+    if (n_full <= 0)
+        return hipSuccess;
+    // remaining strips, from the context's lowest (largest t) to its first: frame rows H-8(t+1) .. H-8t, ascending
+    const int t_low = c->il_phase + (n_full - 1) * c->il_period;
+    unsigned char *d = frame + (size_t)(c->H - 8 * (t_low + 1)) * row;
+    return hipMemcpy2DAsync(d, (size_t)c->il_period * 8 * row, s, 8 * row, 8 * row, (size_t)n_full, hipMemcpyDeviceToDevice, st);
+}
+
+} // namespace
+
+int ptrt_farm_create(ptrt_ctx *const *bands, int n_bands, ptrt_farm **out) {
+    if (!out)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_create: out is NULL");
+    *out = nullptr;
+    if (!bands || n_bands < 1)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_create: no contexts");
+    for (int i = 0; i < n_bands; ++i)
+        if (!ctx_live(bands[i]))
+            return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_create: context %d is not a live context", i);
+    const int W = bands[0]->W, H = bands[0]->H;
+    // the contexts must tile the frame exactly once
+    std::vector<int> owner((size_t)H, -1);
+    for (int i = 0; i < n_bands; ++i) {
+        const ptrt_ctx *c = bands[i];
+        if (c->W != W || c->H != H)
+            return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_create: context %d renders a %dx%d frame, context 0 %dx%d", i, c->W, c->H, W, H);
+        if (c->scaled())
+            return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_create: context %d has a reduced render size", i);
+        for (int yl = 0; yl < c->rows; ++yl) {
+            const int y = c->il_period > 1 ? ((((yl >> 3) * c->il_period + c->il_phase) << 3) | (yl & 7)) : c->y0 + yl;
+            if (y < 0 || y >= H || owner[(size_t)y] >= 0)
+                return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_create: row %d is rendered by contexts %d and %d (or lies outside the frame)",
+                            y, y >= 0 && y < H ? owner[(size_t)y] : -1, i);
+            owner[(size_t)y] = i;
+        }
+    }
+    for (int y = 0; y < H; ++y)
+        if (owner[(size_t)y] < 0)
+            return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_create: no context renders row %d", y);
+
+    ptrt_farm *f = new ptrt_farm;
+    f->band.assign(bands, bands + n_bands);
+    f->W = W;
+    f->H = H;
+    f->device = bands[0]->device;
+    f->rendered.assign((size_t)n_bands, nullptr);
+    f->taken.assign((size_t)n_bands, nullptr);
+    f->staging.assign((size_t)n_bands, nullptr);
+    f->comm_rank.assign((size_t)n_bands, -1);
+    auto bail = [&](int code, const std::string &msg) {
+        farm_free(f);
+        return fail(nullptr, code, "ptrt_farm_create: %s", msg.c_str());
+    };
+    hipError_t e = hipSetDevice(f->device);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+    if (e != hipSuccess)
+        return bail(PTRT_E_HIP, hipGetErrorString(e));
+    // devices other than the presenting one talk to it over RCCL: one communicator per distinct device
+    f->comm_dev.push_back(f->device);
+    for (int i = 0; i < n_bands; ++i) {
+        const int d = bands[i]->device;
+        if (d == f->device)
+            continue;
+        size_t k = 0;
+        while (k < f->comm_dev.size() && f->comm_dev[k] != d)
+            ++k;
+        if (k == f->comm_dev.size())
+            f->comm_dev.push_back(d);
+        f->comm_rank[(size_t)i] = (int)k;
+    }
+    if (f->comm_dev.size() > 1) {
+        if (!rccl().ok)
+            return bail(PTRT_E_HIP, "contexts on several devices need RCCL (librccl.so), which could not be loaded");
+        f->comms.assign(f->comm_dev.size(), nullptr);
+        const ncclResult_t r = rccl().CommInitAll(f->comms.data(), (int)f->comm_dev.size(), f->comm_dev.data());
+        if (r != ncclSuccess)
+            return bail(PTRT_E_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r));
+        f->transport = "rccl";
+    }
+    for (int i = 0; i < n_bands; ++i) {
+        e = hipSetDevice(bands[i]->device);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&f->rendered[(size_t)i], hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&f->taken[(size_t)i], hipEventDisableTiming);
+        if (e == hipSuccess && f->comm_rank[(size_t)i] >= 0) {
+            e = hipSetDevice(f->device);
+            if (e == hipSuccess)
+                e = hipMalloc((void **)&f->staging[(size_t)i], bands[i]->npix * 3);
+        }
+        if (e != hipSuccess)
+            return bail(PTRT_E_HIP, hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_farm_mutex);
+        g_farms.insert(f);
+    }
+    *out = f;
+    return PTRT_OK;
+}
+
+int ptrt_farm_bands(const ptrt_farm *f) { return farm_live(const_cast<ptrt_farm *>(f)) ? (int)f->band.size() : 0; }
+
+const char *ptrt_farm_transport(const ptrt_farm *f) { return farm_live(const_cast<ptrt_farm *>(f)) ? f->transport.c_str() : ""; }
+
+// Gathers the contexts' current RGB8 images (rendered with a NULL target) into the frame.
+int ptrt_farm_gather(ptrt_farm *f, void *out_rgb8, int out_is_device) {
+    if (!farm_live(f) || !out_rgb8)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_gather: bad argument");
+    for (ptrt_ctx *c : f->band)
+        if (!ctx_live(c))
+            return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_gather: a context of the farm has been destroyed");
+    const size_t frame_bytes = (size_t)f->W * f->H * 3;
+    unsigned char *frame = (unsigned char *)out_rgb8;
+    HIP_TRY(nullptr, hipSetDevice(f->device));
+    if (!out_is_device) {
+        if (!f->d_frame)
+            HIP_TRY(nullptr, hipMalloc((void **)&f->d_frame, frame_bytes));
+        frame = f->d_frame;
+    }
+    const size_t n = f->band.size();
+    // remote images: sends on the contexts' streams (behind their render), receives on the farm's stream, one group
+    if (!f->comms.empty()) {
+        ncclResult_t r = rccl().GroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
+            ptrt_ctx *c = f->band[i];
+            const int k = f->comm_rank[i];
+            if (k < 0)
+                continue;
+            r = rccl().Send(c->d_rgb8, c->npix * 3, ncclUint8, 0, f->comms[(size_t)k], c->stream);
+            if (r == ncclSuccess)
+                r = rccl().Recv(f->staging[i], c->npix * 3, ncclUint8, k, f->comms[0], f->stream);
+        }
+        const ncclResult_t r2 = rccl().GroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess)
+            return fail(nullptr, PTRT_E_HIP, "ptrt_farm_gather: RCCL: %s", rccl().GetErrorString(r != ncclSuccess ? r : r2));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        ptrt_ctx *c = f->band[i];
+        const unsigned char *src = f->staging[i];
+        if (f->comm_rank[i] < 0) { // on the presenting device: behind the context's render
+            HIP_TRY(nullptr, hipSetDevice(c->device));
+            HIP_TRY(nullptr, hipEventRecord(f->rendered[i], c->stream));
+            HIP_TRY(nullptr, hipSetDevice(f->device));
+            HIP_TRY(nullptr, hipStreamWaitEvent(f->stream, f->rendered[i], 0));
+            src = c->d_rgb8;
+        }
+        HIP_TRY(nullptr, place_image(c, src, frame, f->stream));
+        if (f->comm_rank[i] < 0) { // its next render must not overwrite the image before it has been taken
+            HIP_TRY(nullptr, hipEventRecord(f->taken[i], f->stream));
+            HIP_TRY(nullptr, hipSetDevice(c->device));
+            HIP_TRY(nullptr, hipStreamWaitEvent(c->stream, f->taken[i], 0));
+            HIP_TRY(nullptr, hipSetDevice(f->device));
+        }
+    }
+    if (!out_is_device) {
+        HIP_TRY(nullptr, hipMemcpyAsync(out_rgb8, frame, frame_bytes, hipMemcpyDeviceToHost, f->stream));
+        HIP_TRY(nullptr, hipStreamSynchronize(f->stream));
+    }
+    return PTRT_OK;
+}
+
+// One frame: every context renders its rows (asynchronously, each on its device), then the gather.
+int ptrt_farm_render(ptrt_farm *f, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
+    if (!farm_live(f))
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_render: bad farm");
+    for (ptrt_ctx *c : f->band)
+        if (int rc = ptrt_render(c, frame_index, spp, max_depth, nullptr, 0))
+            return rc;
+    return ptrt_farm_gather(f, out_rgb8, out_is_device);
+}
+
+// waits until the last gathered frame is complete on the presenting device
+int ptrt_farm_sync(ptrt_farm *f) {
+    if (!farm_live(f))
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_sync: bad farm");
+    HIP_TRY(nullptr, hipSetDevice(f->device));
+    HIP_TRY(nullptr, hipStreamSynchronize(f->stream));
+    return PTRT_OK;
+}
+
+void ptrt_farm_destroy(ptrt_farm *f) {
+    {
+        std::lock_guard<std::mutex> lock(g_farm_mutex);
+        if (!f || !g_farms.count(f))
+            return;
+        g_farms.erase(f);
+    }
+    farm_free(f);
+}

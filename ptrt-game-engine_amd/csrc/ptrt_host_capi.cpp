@@ -4,6 +4,7 @@
 // Scene method; C++ exceptions become negative return codes + hs_last_error().
 #include "../host/ptrt/scene.hpp"
 #include "../host/ptrt/serialize.hpp"
+#include "../host/ptrt/farm.hpp"
 #include "../host/ptrt/view.hpp"
 
 #include <chrono>
@@ -80,6 +81,15 @@ void *hs_scene_create(int w, int h, int tile_y0, int tile_rows, int device) {
         return nullptr;
     }
 }
+void *hs_scene_create_interleaved(int w, int h, int phase, int period, int device) {
+    try {
+        return new Scene(w, h, Scene::Interleave{phase, period}, device);
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+int hs_tile_rows(void *s) { return static_cast<Scene *>(s)->getTileRows(); }
 void hs_scene_destroy(void *s) { delete static_cast<Scene *>(s); }
 void *hs_backend(void *s) { return static_cast<Scene *>(s)->backend(); }
 
@@ -355,6 +365,27 @@ const ptrt_scene_desc *hs_flatten(void *s) {
     }
 }
 
+
+// C++ TileFarm (host/ptrt/farm.hpp) from Python: `n` parts on `devices`, scene built by `recipe` (0 Cornell-like
+// cubes are built by the caller through hs_farm_scene); returns the farm or NULL
+void *hs_farm_create(int w, int h, const int *devices, int n, int strips) {
+    try {
+        return new TileFarm(w, h, std::vector<int>(devices, devices + n), strips ? TileFarm::Strips : TileFarm::Bands,
+                            [](Scene &) {});
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void *hs_farm_scene(void *f, int i) { return &static_cast<TileFarm *>(f)->scene((size_t)i); }
+int hs_farm_size(void *f) { return (int)static_cast<TileFarm *>(f)->size(); }
+const char *hs_farm_transport(void *f) { return static_cast<TileFarm *>(f)->transport(); }
+int hs_farm_render(void *f, unsigned char *pixels, int is_device) {
+    HS_TRY(is_device ? static_cast<TileFarm *>(f)->render_to_device(pixels) : static_cast<TileFarm *>(f)->render_to_host(pixels));
+    return 0;
+}
+int hs_farm_sync(void *f) { HS_TRY(static_cast<TileFarm *>(f)->sync()); return 0; }
+void hs_farm_destroy(void *f) { delete static_cast<TileFarm *>(f); }
 
 // canonical byte stream of the flattened scene (host/ptrt/serialize.hpp); returns its length, copies
 // min(length, cap) bytes

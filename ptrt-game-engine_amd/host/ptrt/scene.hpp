@@ -267,6 +267,37 @@ class Scene {
         }
         prev_view_proj = camera.get_view_proj();
     }
+    // Tile farm, second way of cutting the frame: this scene renders every `period`-th 8-row strip starting with
+    // strip `phase` (ptrt_create_interleaved).  No post chain, like a band.
+    struct Interleave {
+        int phase, period;
+    };
+    Scene(int w, int h, Interleave il, int device = PTRT_DEFAULT_DEVICE)
+        : width(w), height(h), camera(static_cast<float>(w) / h, 2.0f, 1.0f) {
+        tileY0 = il.phase * 8;
+        device_ = device;
+        render_width = w;
+        render_height = h;
+        tileRows = 0;
+        for (int t = il.phase; t * 8 < h; t += (il.period < 1 ? 1 : il.period))
+            tileRows += (t * 8 + 8 <= h) ? 8 : h - t * 8;
+        if (device < 0)
+            return;
+        if (ptrt_create_interleaved(w, h, il.phase, il.period, device, &ctx) != PTRT_OK) {
+            std::string msg = std::string("Failed to create GPU context: ") + ptrt_last_error(ctx);
+            ptrt_destroy(ctx);
+            ctx = nullptr;
+            throw std::runtime_error(msg);
+        }
+        try {
+            check(ptrt_reset_rng(ctx, PTRT_DEFAULT_SEED), "Failed to init rand states");
+        } catch (...) {
+            ptrt_destroy(ctx);
+            ctx = nullptr;
+            throw;
+        }
+        prev_view_proj = camera.get_view_proj();
+    }
     ~Scene() { ptrt_destroy(ctx); }
     Scene(const Scene &) = delete;
     Scene &operator=(const Scene &) = delete;

@@ -144,6 +144,23 @@ _sig("hs_last_error", C.c_char_p)
 _sig("hs_material_default", None, _fp)
 _sig("hs_material_make", None, _fp, C.c_float, C.c_float, _fp)
 _sig("hs_scene_create", _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("hs_scene_create_interleaved", _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("hs_tile_rows", C.c_int, _vp)
+_sig("hs_farm_create", _vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int)
+_sig("hs_farm_scene", _vp, _vp, C.c_int)
+_sig("hs_farm_size", C.c_int, _vp)
+_sig("hs_farm_transport", C.c_char_p, _vp)
+_sig("hs_farm_render", C.c_int, _vp, _vp, C.c_int)
+_sig("hs_farm_sync", C.c_int, _vp)
+_sig("hs_farm_destroy", None, _vp)
+_sig("ptrt_create_interleaved", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp))
+_sig("ptrt_farm_create", C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp))
+_sig("ptrt_farm_bands", C.c_int, _vp)
+_sig("ptrt_farm_transport", C.c_char_p, _vp)
+_sig("ptrt_farm_render", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int)
+_sig("ptrt_farm_gather", C.c_int, _vp, _vp, C.c_int)
+_sig("ptrt_farm_sync", C.c_int, _vp)
+_sig("ptrt_farm_destroy", None, _vp)
 _sig("hs_scene_destroy", None, _vp)
 _sig("hs_backend", _vp, _vp)
 _sig("hs_init_blue_noise", C.c_int, _vp)
@@ -279,18 +296,38 @@ def blue_noise_table():
 class Scene:
     """The reference's `Scene` host API; see host/ptrt/scene.hpp for per-method citations."""
 
-    def __init__(self, width, height, tile_y0=0, tile_rows=0, device=0):
+    def __init__(self, width, height, tile_y0=0, tile_rows=0, device=0, interleave=None):
+        """`interleave=(phase, period)`: the scene renders every period-th 8-row strip of the frame from strip `phase`
+        (ptrt_create_interleaved) instead of the contiguous rows [tile_y0, tile_y0 + tile_rows)."""
         self.width, self.height = int(width), int(height)
+        self.device = device
+        self.interleave = interleave
+        if interleave is not None:
+            phase, period = interleave
+            self._h = lib.hs_scene_create_interleaved(self.width, self.height, int(phase), int(period), device)
+            if not self._h:
+                raise PtrtError(lib.hs_last_error().decode())
+            self.tile_y0, self.tile_rows = int(phase) * 8, lib.hs_tile_rows(self._h)
+            return
         self.tile_y0 = int(tile_y0)
         self.tile_rows = int(tile_rows) if tile_rows > 0 else self.height
-        self.device = device
         self._h = lib.hs_scene_create(self.width, self.height, tile_y0, tile_rows, device)
         if not self._h:
             raise PtrtError(lib.hs_last_error().decode())
 
+    @classmethod
+    def _borrowed(cls, handle, width, height, device):
+        """A Scene owned by someone else (a C++ TileFarm's part): same methods, never destroyed from here."""
+        s = cls.__new__(cls)
+        s._h, s._owned = handle, False
+        s.width, s.height, s.device, s.interleave = int(width), int(height), device, None
+        s.tile_y0, s.tile_rows = 0, lib.hs_tile_rows(handle)
+        return s
+
     def close(self):
         if getattr(self, "_h", None):
-            lib.hs_scene_destroy(self._h)
+            if getattr(self, "_owned", True):
+                lib.hs_scene_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -558,6 +595,50 @@ class Scene:
         if not p:
             raise PtrtError(lib.hs_last_error().decode())
         return p
+
+
+class TileFarm:
+    """host/ptrt/farm.hpp from Python: one C++ Scene per entry of `devices` (bands, or interleaved 8-row strips),
+    their images gathered below the C ABI (ptrt_farm_*: device copies on the presenting GPU, RCCL from the others)."""
+
+    def __init__(self, width, height, devices, strips=False):
+        self.width, self.height = int(width), int(height)
+        arr = (C.c_int * len(devices))(*devices)
+        self._f = lib.hs_farm_create(self.width, self.height, arr, len(devices), int(bool(strips)))
+        if not self._f:
+            raise PtrtError(lib.hs_last_error().decode())
+        self.scenes = [Scene._borrowed(lib.hs_farm_scene(self._f, i), width, height, devices[i]) for i in range(len(devices))]
+
+    @property
+    def transport(self):
+        return lib.hs_farm_transport(self._f).decode()
+
+    def render_to_device(self, ptr):
+        if lib.hs_farm_render(self._f, ptr, 1) < 0:
+            raise PtrtError(lib.hs_last_error().decode())
+
+    def render_to_host(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        if lib.hs_farm_render(self._f, out.ctypes.data_as(_vp), 0) < 0:
+            raise PtrtError(lib.hs_last_error().decode())
+        return out
+
+    def sync(self):
+        if lib.hs_farm_sync(self._f) < 0:
+            raise PtrtError(lib.hs_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_f", None):
+            for s in self.scenes:
+                s.close()
+            lib.hs_farm_destroy(self._f)
+            self._f = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 from . import scenes  # noqa: E402,F401

@@ -186,6 +186,34 @@ def showcase(scene, segments=71):
     return scene
 
 
+def million(scene, segments=250):
+    """The workload of the reference's only published numbers ("a scene with about 1 million triangles, and 8 separate
+    models", Test game screenshots/readme.txt:16-19; the models themselves are not in the repository): 8 x
+    addSphere(250) = 8 x 125,000 triangles in the showcase arrangement (materials, lights, camera, floor of scene 8,
+    app_utils.cuh:585-679) -- nine meshes, a single-leaf TLAS."""
+    floor_y = 2.0 - 10.0 / 2.0
+    mats = _showcase_materials()
+    xs = (-6, -2, 2, 6)
+    for i in range(8):
+        mesh = scene.addSphere(segments, mats[(i * 5) % 10 if i % 2 else i])
+        scene.scale(mesh, 3.0)
+        scene.moveTo(mesh, (xs[i % 4], floor_y + 3.0, -12 if i < 4 else -8))
+        scene.rotateSelfEulerXYZ(mesh, (0, 0.3, 0))
+    scene.addPlaneXZ(floor_y, 50.0, Material((0.4, 0.4, 0.4), 0.9, specular=(0.0, 0.0, 0.0)))
+    scene.setSkyGradient((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    one = (1.0, 1.0, 1.0)
+    scene.addSpotLight((0, 6.5, -10), (0, -1, 0), one, 15.0, 0.1, 0.8, 2.0, 0.1)
+    scene.addSpotLight((-6, 6.5, -10), (0, -1, 0), one, 12.0, 0.1, 0.8, 2.0, 0.1)
+    scene.addSpotLight((6, 6.5, -10), (0, -1, 0), one, 12.0, 0.1, 0.8, 2.0, 0.1)
+    scene.addPointLight((0, 2, 4), (0.8, 0.8, 0.8), 5.0, 20.0, 0.1)
+    scene.addPointLight((-8, 1, 4), (0.5, 0.5, 0.5), 3.0, 20.0, 0.1)
+    scene.addPointLight((8, 1, 4), (0.5, 0.5, 0.5), 3.0, 20.0, 0.1)
+    cam_pos, cam_at = (0.0, 2.0, 5.0), (0.0, 0.0, -10.0)
+    focus = math.sqrt(sum((a - b) ** 2 for a, b in zip(cam_at, cam_pos)))
+    scene.setCamera(cam_pos, cam_at, (0, 1, 0), 50.0, 0.0, focus)
+    return scene
+
+
 _WAVES = ((0.35, (0.45, 0.20), 1.3), (0.20, (-0.30, 0.55), 2.1), (0.12, (0.80, -0.65), 3.4))
 
 

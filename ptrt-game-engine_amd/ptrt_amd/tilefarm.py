@@ -23,6 +23,44 @@ def bands(height, world):
     return out
 
 
+def strip_rows(height, world, rank):
+    """Frame rows (top-down) of the context that owns every world-th 8-row strip from strip `rank`
+    (ptrt_create_interleaved): what balances a frame whose cost is uneven over its height."""
+    rows = []
+    for t in range(rank, (height + 7) // 8, world):
+        rows.extend(range(8 * t, min(8 * t + 8, height)))
+    return rows
+
+
+def strip_frame_index(height, world, rank):
+    """For the bottom-up RGB8 image of that context: the frame's (bottom-up) byte row of each of its byte rows."""
+    rows = strip_rows(height, world, rank)
+    return [height - 1 - y for y in reversed(rows)]
+
+
+def max_strip_rows(height, world):
+    return max(len(strip_rows(height, world, r)) for r in range(world))
+
+
+def gather_strips(dist, tile, frame, parts, index, rank, world, async_op=False):
+    """Collective for the strip layout: every rank contributes its (max_rows, W, 3) image (its rows first, padding
+    behind); rank 0 receives all into `parts` and scatters the valid rows into `frame` (index[r]: LongTensor of frame
+    rows).  With async_op the scatter is the caller's (`scatter_strips`) after .wait()."""
+    if world == 1:
+        return None
+    w = dist.gather(tile, parts if rank == 0 else None, dst=0, async_op=async_op)
+    if async_op:
+        return _Works([w])
+    if rank == 0:
+        scatter_strips(frame, parts, index)
+    return None
+
+
+def scatter_strips(frame, parts, index):
+    for r, idx in enumerate(index):
+        frame.index_copy_(0, idx, parts[r][:idx.numel()])
+
+
 def frame_views(frame, height, world):
     """Views into a (H, W, 3) uint8 frame, one per rank, where that rank's band image lands."""
     return [frame[height - (y0 + rows):height - y0] for (y0, rows) in bands(height, world)]

@@ -1,0 +1,80 @@
+"""The tile farm below the C ABI (ptrt_farm_*, host/ptrt/farm.hpp): several band / strip contexts of one process, their
+RGB8 images gathered onto the presenting device, give the bytes of the full-frame context.  On this one-GPU box every
+part sits on device 0 (transport "device-copy"); parts on other devices take the RCCL path, which only a multi-GPU
+node exercises (unmeasured here)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _prep(P, s, build, spp=2, depth=4):
+    build(s)
+    s.setPerfSamplesPerPixel(spp)
+    s.setMaxBounceDepth(depth)
+    s.setDenoiserEnabled(False)
+    s.setBloomEnabled(False)
+    s.initBlueNoise()
+    s.uploadToGPU()
+
+
+@pytest.mark.parametrize("strips", [False, True])
+@pytest.mark.parametrize("size,parts", [((96, 64), 4), ((104, 77), 3), ((64, 68), 8)])
+def test_cpp_tile_farm_equals_the_full_frame(P, size, parts, strips):
+    """77 rows: the frame's last strip is short; 68 rows / 8 parts: nine strips, the short last one owned by part 0 (bands of 8 and 12 rows)."""
+    W, H = size
+    build = lambda s: P.scenes.showcase(s, segments=10)
+    full = P.Scene(W, H)
+    _prep(P, full, build)
+    want = [full.render_to_host() for _ in range(3)]
+    full.close()
+    farm = P.TileFarm(W, H, [0] * parts, strips=strips)
+    assert farm.transport == "device-copy" and len(farm.scenes) == parts
+    assert sum(s.tile_rows for s in farm.scenes) == H
+    for s in farm.scenes:
+        _prep(P, s, build)
+    import torch
+    dev = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    for f in range(3):
+        if f == 1:  # device target, no host synchronisation inside the frame
+            farm.render_to_device(dev.data_ptr())
+            farm.sync()
+            got = dev.cpu().numpy()
+        else:
+            got = farm.render_to_host()
+        assert np.array_equal(got, want[f]), f"frame {f}: {(got != want[f]).sum()} bytes differ"
+    farm.close()
+
+
+def test_c_abi_farm_over_interleaved_contexts_and_bad_tilings(P):
+    W, H = 80, 52
+    build = P.scenes.cornell
+    full = P.Scene(W, H)
+    _prep(P, full, build, spp=1)
+    want = full.render_to_host()
+    full.close()
+    parts = [P.Scene(W, H, interleave=(r, 3)) for r in range(3)]
+    for s in parts:
+        _prep(P, s, build, spp=1)
+    ctxs = (C.c_void_p * 3)(*[s.ctx for s in parts])
+    farm = C.c_void_p()
+    assert P.lib.ptrt_farm_create(ctxs, 3, C.byref(farm)) == 0 and P.lib.ptrt_farm_bands(farm) == 3
+    out = np.zeros((H, W, 3), np.uint8)
+    assert P.lib.ptrt_farm_render(farm, 0, 1, 4, out.ctypes.data_as(C.c_void_p), 0) == 0
+    assert np.array_equal(out, want)
+    # the strips of an interleaved context, top-down, are rows 8(phase + 3k) .. +7 of the frame
+    acc = [s.read(P.BUF_OBJECT_ID).reshape(-1, W) for s in parts]
+    assert [a.shape[0] for a in acc] == [20, 16, 16]  # 52 rows = strips 0..6, the last one 4 rows: phase 0 owns 0, 3, 6
+    P.lib.ptrt_farm_destroy(farm)
+    # two of three phases do not tile the frame; nor do overlapping bands
+    bad = C.c_void_p()
+    assert P.lib.ptrt_farm_create((C.c_void_p * 2)(parts[0].ctx, parts[1].ctx), 2, C.byref(bad)) == -1 and not bad.value
+    assert b"no context renders row" in P.lib.ptrt_last_error(None)
+    a, b = P.Scene(W, H, tile_y0=0, tile_rows=30), P.Scene(W, H, tile_y0=26, tile_rows=26)
+    assert P.lib.ptrt_farm_create((C.c_void_p * 2)(a.ctx, b.ctx), 2, C.byref(bad)) == -1
+    assert b"rendered by contexts" in P.lib.ptrt_last_error(None)
+    for s in parts + [a, b]:
+        s.close()
+    P.lib.ptrt_farm_destroy(None)

@@ -221,6 +221,15 @@ def upscale(image, out_w, out_h, in_w, in_h):
     return out
 
 
+def mat3_mul(m9, v3):
+    """mat3 * vec3 as the oracle's aces_tonemap forms it (matrix.cuh:35-39)."""
+    m = np.ascontiguousarray(m9, dtype=np.float32).reshape(9)
+    v = np.ascontiguousarray(v3, dtype=np.float32).reshape(3)
+    out = np.zeros(3, np.float32)
+    lib.oracle_mat3_mul(_f(m), _f(v), _f(out))
+    return out
+
+
 def taa_jitter(frame_index):
     out = np.zeros(2, np.float32)
     lib.oracle_taa_jitter(int(frame_index), _f(out))

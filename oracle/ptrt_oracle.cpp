@@ -1656,6 +1656,15 @@ void oracle_any_hit(const ptrt_scene_desc *scene, const float *origins, const fl
 /* taa.cuh:41-61, exposed so tests can set it beside the reference's own getTAAJitter (oracle/_ref) */
 void oracle_taa_jitter(int frame_index, float *out2) { getTAAJitter(frame_index, out2[0], out2[1]); }
 
+/* mat3 * vec3 exactly as aces_tonemap forms it (matrix.cuh:35-39), exposed for the known-answer test against the
+ * reference's own mat3 (oracle/_ref, tests/test_ref_probe.py) */
+void oracle_mat3_mul(const float *m9, const float *v3, float *out3) {
+    const V3 r = mat3_mul(m9, V3(v3[0], v3[1], v3[2]));
+    out3[0] = r.x;
+    out3[1] = r.y;
+    out3[2] = r.z;
+}
+
 /* deterministic math, exposed for tests: op 0 sin, 1 cos, 2 exp, 3 log, 4 pow(x,y) */
 void oracle_detmath(int op, const float *x, const float *y, int n, float *out) {
     for (int i = 0; i < n; ++i) {

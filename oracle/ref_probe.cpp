@@ -7,6 +7,7 @@
 //   pathtracer/rendering/taa.cuh:19-61   Halton-16 table + getTAAJitter
 //   pathtracer/scene/lights.cuh:12-22    Light (layout the C ABI's ptrt_light mirrors)
 //   common/vec3.cuh, common/ray.cuh      vec3 / Ray layout, vec3's host-side arithmetic (known answers)
+//   common/matrix.cuh:8-90               mat3: the 3x3 products of the ACES tonemap (render_utils.cuh:77-95)
 //
 // Everything else on the path includes <curand_kernel.h> (pathtracer/math/mathutils.cuh:11, pulled
 // in by common/mat4.cuh:6), which the image lacks, so it is unbuildable here and stays
@@ -18,6 +19,7 @@
 #include "common/vec3.cuh"
 #include "common/ray.cuh"
 #include "common/bluenoise.cuh"
+#include "common/matrix.cuh"
 #include "pathtracer/rendering/taa.cuh"
 #include "pathtracer/scene/lights.cuh"
 
@@ -80,6 +82,31 @@ int main(int argc, char **argv) {
         printf("%s[%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u]", k ? "," : "", bits(dot(a, b)), bits(a.length()),
                bits(a.length_squared()), bits(c.x), bits(c.y), bits(c.z), bits(n.x), bits(n.y), bits(n.z), bits(r.x), bits(r.y),
                bits(r.z), bits(l.x), bits(l.y), bits(l.z), bits(q.x), bits(q.y), bits(q.z));
+    }
+    printf("],\n");
+    // common/matrix.cuh: mat3 * vec3, mat3 * mat3, transpose, determinant, inverse on 24 seeded matrices / vectors
+    // (the tonemap multiplies the colour by two constant mat3s: render_utils.cuh:78-91)
+    printf(" \"mat3_kat\": [");
+    for (int k = 0; k < 24; ++k) {
+        float a[9], b[9];
+        for (float &x : a) x = rnd();
+        for (float &x : b) x = rnd() * 0.25f;
+        const vec3 v(rnd(), rnd(), rnd());
+        const mat3 A(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]), B(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8]);
+        const vec3 av = A * v;
+        const mat3 ab = A * B, at = A.transpose(), ai = A.inverse();
+        printf("%s{\"a\":[", k ? "," : "");
+        for (int i = 0; i < 9; ++i) printf("%s%u", i ? "," : "", bits(a[i]));
+        printf("],\"b\":[");
+        for (int i = 0; i < 9; ++i) printf("%s%u", i ? "," : "", bits(b[i]));
+        printf("],\"v\":[%u,%u,%u],\"av\":[%u,%u,%u],\"det\":%u,\"ab\":[", bits(v.x), bits(v.y), bits(v.z), bits(av.x), bits(av.y),
+               bits(av.z), bits(A.determinant()));
+        for (int i = 0; i < 9; ++i) printf("%s%u", i ? "," : "", bits(ab.m[i / 3][i % 3]));
+        printf("],\"at\":[");
+        for (int i = 0; i < 9; ++i) printf("%s%u", i ? "," : "", bits(at.m[i / 3][i % 3]));
+        printf("],\"ai\":[");
+        for (int i = 0; i < 9; ++i) printf("%s%u", i ? "," : "", bits(ai.m[i / 3][i % 3]));
+        printf("]}");
     }
     printf("]\n}\n");
     return 0;

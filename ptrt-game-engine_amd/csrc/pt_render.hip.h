@@ -1509,11 +1509,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         K.accum[idx * 3 + 0] = out.x;
         K.accum[idx * 3 + 1] = out.y;
         K.accum[idx * 3 + 2] = out.z;
-        // tonemap_kernel fused: RGB8, rows flipped within the tile (scene.cuh:2013-2015); skipped
-        // (wave-uniform) when a denoiser / bloom / up-scale stage follows and tonemaps its own result
-        if (K.rgb8) {
-            unsigned char r8, g8, b8;
-            tonemap_pixel(out, r8, g8, b8);
+        // (tonemap_kernel fused, below: RGB8, rows flipped within the tile (scene.cuh:2013-2015); skipped -- wave-uniform --
+        // when a denoiser / bloom / up-scale stage follows and tonemaps its own result)
+    }
+    if (K.rgb8) {
+        // A tile row is 8 pixels = 24 contiguous bytes of the bottom-up image.  Full tiles of a frame whose rows are
+        // dword-aligned leave as six dwords per row: lane c < 6 of a row takes the (at most two) pixels its dword
+        // spans out of their lanes' registers (ds_bpermute), instead of three byte stores per lane.
+        const int x = px(), yl = pyl();
+        unsigned char r8 = 0, g8 = 0, b8 = 0;
+        if (inside)
+            tonemap_pixel(avg_color / (float)K.spp, r8, g8, b8);
+        const bool full_tile = (tx * 8 + 8 <= K.width) && (ty * 8 + 8 <= K.rows) && (K.width % 4 == 0) &&
+                               (((size_t)K.rgb8 & 3u) == 0u);
+        if (full_tile) {
+            const uint32_t pix = (uint32_t)r8 | ((uint32_t)g8 << 8) | ((uint32_t)b8 << 16);
+            const int c = lane & 7, first = (4 * c) / 3;                 // first pixel of dword c; byte offset in it: (4c) % 3
+            const int src = (lane & ~7) | (first < 7 ? first : 7), src1 = (lane & ~7) | (first + 1 < 7 ? first + 1 : 7);
+            const unsigned long long two = (unsigned long long)(uint32_t)__shfl((int)pix, src) |
+                                           ((unsigned long long)(uint32_t)__shfl((int)pix, src1) << 24);
+            if (c < 6) {
+                uint32_t *row = (uint32_t *)(K.rgb8 + ((size_t)(K.rows - 1 - yl) * K.width + (size_t)tx * 8) * 3);
+                row[c] = (uint32_t)(two >> (8 * ((4 * c) % 3)));
+            }
+        } else if (inside) {
             const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
             K.rgb8[o + 0] = r8;
             K.rgb8[o + 1] = g8;

@@ -8,6 +8,8 @@
 #include "math.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -92,54 +94,111 @@ class Mesh {
             faces.push_back({f[0], f[1], f[2]});
     }
 
-    // Wavefront OBJ: `v` and `f` records only, polygons fanned, negative indices
-    // relative, a/b/c index forms accepted, vertices re-centred on their mean
-    // (mesh.cuh:238-323).
+    // Wavefront OBJ (the reader behind Scene::addMesh, mesh.cuh:238-323).  What the reference accepts is kept -- only
+    // `v x y z` and `f ...` records count; a face corner is `i`, `i/t`, `i//n` or `i/t/n` of which only `i` is used,
+    // 1-based or negative = relative to the vertices read so far; polygons are fanned around their first corner;
+    // the vertices are re-centred on their mean (summed in double); the three error messages -- but the file is read
+    // in one piece and scanned with a cursor instead of line by line through string streams.
     explicit Mesh(const std::string &path) {
-        std::ifstream in(path);
-        if (!in)
-            throw std::runtime_error("Mesh: cannot open " + path);
-        double sx = 0, sy = 0, sz = 0;
-        size_t nv = 0;
-        std::string line, key;
-        std::vector<int> idx;
-        while (std::getline(in, line)) {
-            if (line.empty() || line[0] == '#')
-                continue;
-            std::istringstream ss(line);
-            ss >> key;
-            if (key == "v") {
+        std::string text;
+        {
+            std::ifstream in(path, std::ios::binary);
+            if (!in)
+                throw std::runtime_error("Mesh: cannot open " + path);
+            in.seekg(0, std::ios::end);
+            const std::streamoff size = in.tellg();
+            in.seekg(0, std::ios::beg);
+            text.resize(size > 0 ? (size_t)size : 0);
+            if (!text.empty())
+                in.read(&text[0], (std::streamsize)text.size());
+            if (in.bad())
+                throw std::runtime_error("Mesh: hardware error reading " + path);
+            text.resize((size_t)in.gcount());
+        }
+        struct Cursor {
+            const char *p, *eol;
+            void blanks() {
+                while (p < eol && (*p == ' ' || *p == '\t' || *p == '\r'))
+                    ++p;
+            }
+            bool real(float &out) {
+                blanks();
+                if (p >= eol)
+                    return false;
+                char *stop = nullptr;
+                const float v = std::strtof(p, &stop); // (the record's line ends in '\n' or the buffer's NUL)
+                if (stop == p || stop > eol)
+                    return false;
+                p = stop;
+                out = v;
+                return true;
+            }
+            bool integer(int &out) {
+                blanks();
+                const char *q = p;
+                bool neg = false;
+                if (q < eol && (*q == '-' || *q == '+'))
+                    neg = *q++ == '-';
+                if (q >= eol || *q < '0' || *q > '9')
+                    return false;
+                long v = 0;
+                while (q < eol && *q >= '0' && *q <= '9')
+                    v = v * 10 + (*q++ - '0');
+                p = q;
+                out = (int)(neg ? -v : v);
+                return true;
+            }
+        };
+        double sum[3] = {0.0, 0.0, 0.0};
+        std::vector<int> corner;
+        const char *const begin = text.c_str(), *const end = begin + text.size();
+        for (const char *line = begin; line < end;) {
+            const char *eol = static_cast<const char *>(std::memchr(line, '\n', (size_t)(end - line)));
+            if (!eol)
+                eol = end;
+            Cursor c{line, eol};
+            line = eol + 1;
+            c.blanks();
+            const char *key = c.p;
+            while (c.p < c.eol && *c.p != ' ' && *c.p != '\t' && *c.p != '\r')
+                ++c.p;
+            if (c.p - key != 1)
+                continue; // comments, vn / vt / usemtl / ... and empty lines
+            if (*key == 'v') {
                 float x, y, z;
-                ss >> x >> y >> z;
-                if (!ss.fail()) {
+                if (c.real(x) && c.real(y) && c.real(z)) {
                     vertices.emplace_back(x, y, z);
-                    sx += x; sy += y; sz += z;
-                    ++nv;
+                    sum[0] += x;
+                    sum[1] += y;
+                    sum[2] += z;
                 }
-            } else if (key == "f") {
-                idx.clear();
+            } else if (*key == 'f') {
+                corner.clear();
                 int id;
-                while (ss >> id) {
-                    idx.push_back(id < 0 ? (int)nv + id : id - 1);
-                    while (ss.peek() == '/') {
-                        ss.get();
-                        if (ss.peek() == '/')
-                            ss.get();
-                        int skipped;
-                        ss >> skipped;
+                while (c.integer(id)) {
+                    corner.push_back(id < 0 ? (int)vertices.size() + id : id - 1);
+                    while (c.p < c.eol && *c.p == '/') { // texture / normal references: skipped
+                        ++c.p;
+                        if (c.p < c.eol && *c.p == '/')
+                            ++c.p;
+                        int unused;
+                        const char *at = c.p;
+                        if (!(c.p < c.eol && *c.p != ' ' && *c.p != '\t' && c.integer(unused)))
+                            c.p = at;
                     }
                 }
-                for (size_t i = 1; i + 1 < idx.size(); ++i)
-                    faces.push_back({idx[0], idx[i], idx[i + 1]});
+                for (size_t k = 2; k < corner.size(); ++k)
+                    faces.push_back({corner[0], corner[k - 1], corner[k]});
             }
         }
-        if (in.bad())
-            throw std::runtime_error("Mesh: hardware error reading " + path);
         if (vertices.empty() || faces.empty())
             throw std::runtime_error("Mesh: no valid geometry in " + path);
-        const float cx = (float)(sx / nv), cy = (float)(sy / nv), cz = (float)(sz / nv);
-        for (auto &v : vertices) {
-            v.x -= cx; v.y -= cy; v.z -= cz;
+        const double n = (double)vertices.size();
+        const float cx = (float)(sum[0] / n), cy = (float)(sum[1] / n), cz = (float)(sum[2] / n);
+        for (vec3 &v : vertices) {
+            v.x -= cx;
+            v.y -= cy;
+            v.z -= cz;
         }
     }
 

@@ -58,6 +58,8 @@ def test_c_abi_farm_over_interleaved_contexts_and_bad_tilings(P):
     parts = [P.Scene(W, H, interleave=(r, 3)) for r in range(3)]
     for s in parts:
         _prep(P, s, build, spp=1)
+        s.render_to_host()               # the Scene mirror hands camera and sky to its context with the first frame;
+        s.reset_rng(P.DEFAULT_SEED)      # ptrt_farm_render below drives the contexts directly, from the initial states
     ctxs = (C.c_void_p * 3)(*[s.ctx for s in parts])
     farm = C.c_void_p()
     assert P.lib.ptrt_farm_create(ctxs, 3, C.byref(farm)) == 0 and P.lib.ptrt_farm_bands(farm) == 3

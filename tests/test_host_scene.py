@@ -177,3 +177,15 @@ def test_obj_loader(P, tmp_path):
     assert np.allclose(v.mean(0), 0, atol=1e-7) and v.min() == -1.0  # re-centred on the vertex mean
     with pytest.raises(P.PtrtError):
         s.addMesh(str(tmp_path / "missing.obj"), P.Material((1, 1, 1)))
+    # every corner form, CRLF line ends, records to ignore, a short `v` line, exponents, no newline at the end
+    obj2 = tmp_path / "forms.obj"
+    obj2.write_bytes(b"o thing\r\nv 1e0 0 0\r\nv 3 0 0.0\r\nv 3 2 0\r\nv 1 2 -0\r\nv 9 9\r\nvt 0.5 0.5\r\nvn 0 0 1\r\nusemtl m\r\n"
+                     b"f 1//1 2//1 3//1\r\nf 1/2 3/4 4/1\r\n\tf\t-1 -4 -3\r\nf 1 2\r\nf 4 3 2 1")
+    m2 = s.addMesh(str(obj2), P.Material((1, 1, 1)))
+    v2, f2, *_ = np_mesh(s.flatten(), m2)
+    assert v2.shape == (4, 3) and np.allclose(v2.mean(0), 0, atol=1e-7) and np.allclose(v2[0], (-1, -1, 0))
+    assert f2.tolist() == [[0, 1, 2], [0, 2, 3], [3, 0, 1], [3, 2, 1], [3, 1, 0]]
+    empty = tmp_path / "empty.obj"
+    empty.write_text("# nothing\nvn 0 0 1\n")
+    with pytest.raises(P.PtrtError, match="no valid geometry"):
+        s.addMesh(str(empty), P.Material((1, 1, 1)))

@@ -83,3 +83,30 @@ def test_host_mirror_vec3_matches_reference_vec3(tmp_path):
                            "-I" + os.path.join(root, "include"), os.path.join(HERE, "golden", "vec3_kat_mirror.cpp"), "-o", exe])
     rows = [[int(v) for v in line.split()] for line in subprocess.check_output([exe]).decode().splitlines()]
     assert rows == GOLD["vec3_kat"]
+
+
+def test_mat3_of_the_reference_pins_the_tonemap_products(O):
+    """common/matrix.cuh compiled from the reference's own file (oracle/_ref): mat3 * vec3 -- the two products of the
+    ACES tonemap (render_utils.cuh:77-95) -- equals the oracle's mat3_mul bit for bit on 24 seeded matrices; the other
+    members (product, transpose, determinant, inverse) are held as known answers of the same unfused arithmetic."""
+    kat = GOLD["mat3_kat"]
+    assert len(kat) == 24
+    f = lambda bits: np.array(bits, dtype=np.uint32).view(np.float32)
+    for k in kat:
+        a, b, v = f(k["a"]), f(k["b"]), f(k["v"])
+        assert np.array_equal(O.mat3_mul(a, v).view(np.uint32), np.array(k["av"], np.uint32))
+        A, B = a.reshape(3, 3), b.reshape(3, 3)
+        ab = np.zeros((3, 3), np.float32)
+        for i in range(3):
+            for j in range(3):
+                acc = np.float32(0)
+                for t in range(3):
+                    acc = np.float32(acc + np.float32(A[i, t] * B[t, j]))
+                ab[i, j] = acc
+        assert np.array_equal(ab.reshape(9).view(np.uint32), np.array(k["ab"], np.uint32))
+        assert np.array_equal(A.T.reshape(9).view(np.uint32), np.array(k["at"], np.uint32))
+        m = A
+        det = np.float32(np.float32(np.float32(m[0, 0] * np.float32(np.float32(m[1, 1] * m[2, 2]) - np.float32(m[1, 2] * m[2, 1])))
+                                    - np.float32(m[0, 1] * np.float32(np.float32(m[1, 0] * m[2, 2]) - np.float32(m[1, 2] * m[2, 0]))))
+                         + np.float32(m[0, 2] * np.float32(np.float32(m[1, 0] * m[2, 1]) - np.float32(m[1, 1] * m[2, 0]))))
+        assert np.float32(det).view(np.uint32) == np.uint32(k["det"])

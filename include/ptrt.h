@@ -442,6 +442,7 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   pair_trace 0|1        (ray, mesh) pair compaction                  pair_split 0|1  lanes per pair in partial batches
  *   fetch_min 0..64       idle lanes before the pair queue refills     leaf_pairs 0|1  compacted leaf phase
  *   leaf_min 1..64        lanes waiting at a leaf that end the descent steal 0..64     shadow-ray subtree stealing
+ *   lds_nodes 0|1         PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels
  *   merged 0|1            one traversal per loop iteration: a light sample's shadow ray rides with the next extension ray
  *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9
  *   denoiser_active, motion_vectors, use_graphs 0|1 */

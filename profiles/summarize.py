@@ -65,13 +65,13 @@ if len(sys.argv) > 3:
                         kind = m.group(1)
                     m = re.search(r"node steps: .*lanes busy ([0-9.]+) %", line)
                     if m and kind:
-                        lb[f"{kind}_node_loop"] = float(m.group(1)) / 100
+                        lb[f"{kind}_node_loop"] = round(float(m.group(1)) / 100, 4)
                     m = re.search(r"triangle loop: .*lanes busy ([0-9.]+) %", line)
                     if m and kind:
-                        lb[f"{kind}_triangle_loop"] = float(m.group(1)) / 100
+                        lb[f"{kind}_triangle_loop"] = round(float(m.group(1)) / 100, 4)
                     m = re.search(r"persistent loop: .*live lanes ([0-9.]+) %", line)
                     if m:
-                        lb["live_lanes"] = float(m.group(1)) / 100
+                        lb["live_lanes"] = round(float(m.group(1)) / 100, 4)
                 entry["lane_busy"] = lb
     allcfg[cfg] = entry
     json.dump(allcfg, open(path, "w"), indent=1, sort_keys=True)

@@ -78,6 +78,9 @@ struct KParams {
     int leaf_min;       // PMODE 2: lanes waiting at a leaf that end the node loop (64 = all of them)
     int leaf_pairs;     // PMODE 2: leaf phase as compacted (lane, triangle) pairs
     int fetch_min;      // PMODE 2: idle lanes before the wave refills from the pair list (0 = static 64-pair batches)
+    int n_nodes;        // inner nodes in the arena (the LDS-staged variant clamps its copies to them)
+    int top_off;        // WG = 4 variant, A/B: do not read the staged nodes (isolates the cost of the larger workgroups)
+    int n_tiles;        // 8x8-pixel tiles of this launch (the 4-wave variant's last workgroup may own fewer than 4)
     int pair_cap;       // PMODE 4: entries the LDS pair list holds (a multiple of 64, >= 64 * pair_meshes + 64)
     // frame
     Camera cam;
@@ -105,6 +108,8 @@ PT_DEV int global_row(int yl, int y0, int il_period, int il_phase) {
 }
 
 constexpr int MESH_REC_F4 = 12;
+constexpr int TOP_LEVELS = 3;                    // BLAS levels numbered in level order (ptrt_capi.hip convert_tree)
+constexpr int TOP_NODES = (1 << TOP_LEVELS) - 1;  // ... = the first 7 inner nodes of a tree
 constexpr int TLAS_HEAD_F4 = 5; // head + the three rows of the inverse matrix: what the root-box test of an instance needs
 constexpr float T_FAR = 1e30f;
 

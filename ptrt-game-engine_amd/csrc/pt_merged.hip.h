@@ -322,9 +322,9 @@ PT_DEV void trace_merged(const KParams &K, const PairLds &L, int lane, bool ext,
     for (;;) {
         const int s_from = s_next;
         const int P = build_pairs_merged(K, L, lane, first, ext_in, we, sh_in, ws, stmax, s_from, s_next);
-        __syncthreads();
+        wave_sync();
         run_merged_queue(K, L, lane, P, eo, ed, so, sd, stmax, cyc);
-        __syncthreads();
+        wave_sync();
         first = false;
         // (the list is sized so that this is one pass unless nearly every ray touches nearly every mesh)
         if (s_next >= n_mesh || !__builtin_amdgcn_ballot_w64(sh_in && L.occ[lane] == 0u))
@@ -332,7 +332,7 @@ PT_DEV void trace_merged(const KParams &K, const PairLds &L, int lane, bool ext,
     }
     const unsigned long long key = L.best[lane];
     occluded = sh && (L.occ[lane] != 0u);
-    __syncthreads(); // the lists are rebuilt by the next trace
+    wave_sync(); // the lists are rebuilt by the next trace
     h.u = h.v = 0.0f;
     if (!ext || key == ~0ull) {
         h.t = h.t_local = T_FAR;

@@ -44,6 +44,7 @@ struct PairLds {
     float4 *tris;             // pair_tri_slots * 3
     int4 *meshtab;            // per mesh order: {first slot, count, flags, mesh id}
     float4 *meshbox;          // per mesh order: {bmin, root ref}, {bmax, flags}: the mesh record's head, staged once
+    const float4 *topnodes;   // WG = 4 variant: the first TOP_NODES nodes of every mesh of the leaf, [order][node][4], or NULL
     uint32_t *pairs;          // 64 * pair_meshes
     float *ray;               // 6 planes of 64
     unsigned long long *best; // 64
@@ -65,7 +66,7 @@ constexpr int TLAS_FILL_TARGET = 64;
 constexpr int PAIR_PAD = 2; // float4 of padding in front of each mesh's packets in LDS (bank spreading)
 PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_entries = 0, int tlas_leaf = 0,
                               int tlas_depth = 0, int pair_cap = 0) {
-    PairLds l;
+    PairLds l{};
     char *p = (char *)base;
     l.tris = (float4 *)p;
     p += tri_slots ? ((size_t)tri_slots * 48 + (size_t)meshes * PAIR_PAD * 16) : 0;
@@ -92,6 +93,40 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     l.lkey = (unsigned long long *)p;
     p += 512;
     l.owner = (unsigned char *)p;
+    return l;
+}
+
+// PMODE 2 in 256-thread workgroups (path_trace_kernel<.., WG = 4>): mesh table, mesh heads and the top levels of every
+// BLAS are ONE copy per workgroup at the base of its LDS; behind them each wave has its own lists and stacks.
+PT_DEV size_t shared_lds_bytes(int meshes) { return (size_t)meshes * (48 + TOP_NODES * 64); }
+PT_DEV size_t wave_lds_bytes(int meshes, int stack_entries) {
+    return 512 + (size_t)meshes * 128 + 256 + (size_t)stack_entries * 512 + LEAF_PAIR_BYTES;
+}
+PT_DEV PairLds carve_pair_lds_wg(void *base, int wave, int meshes, int stack_entries) {
+    PairLds l{};
+    char *p = (char *)base;
+    l.meshtab = (int4 *)p;
+    p += (size_t)meshes * 16;
+    l.meshbox = (float4 *)p;
+    p += (size_t)meshes * 32;
+    l.topnodes = (const float4 *)p;
+    p += (size_t)meshes * TOP_NODES * 64;
+    p += (size_t)wave * wave_lds_bytes(meshes, stack_entries);
+    l.best = (unsigned long long *)p;
+    p += 512;
+    l.pairs = (uint32_t *)p;
+    p += (size_t)meshes * 128;
+    l.occ = (uint32_t *)p;
+    p += 256;
+    l.stack = (uint2 *)p;
+    p += (size_t)stack_entries * 512;
+    l.lkey = (unsigned long long *)p;
+    p += 512;
+    l.owner = (unsigned char *)p;
+    l.tris = nullptr;
+    l.ray = nullptr;
+    l.tstack = nullptr;
+    l.leafx = nullptr;
     return l;
 }
 
@@ -151,6 +186,12 @@ PT_DEV void wave_lds_order() { // LDS is in order within a wave; this only pins 
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 }
+
+// The pair lists, merge keys and stacks of a trace belong to ONE wave (a 64-thread workgroup, or one wave's slice of
+// a larger workgroup's LDS): between its phases the wave only needs its own LDS operations in program order, which
+// the hardware gives (LDS instructions of a wave complete in order); a workgroup barrier here would also wait for
+// every outstanding global load and store of the wave.
+PT_DEV void wave_sync() { wave_lds_order(); }
 
 PT_DEV int lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -258,7 +299,7 @@ template <bool GEN = false> PT_DEV void pair_ray_from(const KParams &K, const in
 
 PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
     const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
-    __syncthreads();
+    wave_sync();
     for (int c = 0; c < P; c += 64) {
         // a batch that does not fill the wave (the last one) gives every pair 2^sh lanes, each testing every
         // 2^sh-th triangle: 18 left-over pairs cost 6 iterations instead of 12.  The lanes of a pair merge
@@ -305,9 +346,9 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
             __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    __syncthreads();
+    wave_sync();
     const unsigned long long key = L.best[lane];
-    __syncthreads(); // the lists are rebuilt by the next trace
+    wave_sync(); // the lists are rebuilt by the next trace
     Hit h;
     h.u = h.v = 0.0f;
     if (!alive || key == ~0ull) {
@@ -341,7 +382,7 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
     // per-lane tMax travels with the ray: reuse the `best` words as a float plane
     float *tmaxv = (float *)L.best;
     tmaxv[lane] = tMax;
-    __syncthreads();
+    wave_sync();
     for (int c = 0; c < P; c += 64) {
         const int n = (P - c) < 64 ? (P - c) : 64; // 2^sh lanes per pair in a batch that does not fill the wave
         int sh = 0;
@@ -376,9 +417,9 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
         if (valid && found)
             L.occ[r] = 1u;
     }
-    __syncthreads();
+    wave_sync();
     const bool occluded = alive && (L.occ[lane] != 0u);
-    __syncthreads();
+    wave_sync();
     return occluded;
 }
 
@@ -406,12 +447,30 @@ template <bool GEN> PT_DEV int4 pair_mesh(const KParams &K, const PairLds &L, in
     return make_int4(root, 0, flags, j);
 }
 
+// one child-pair node: out of the workgroup's LDS copy if it is one of the tree's first TOP_NODES (WG = 4 variant),
+// else from memory
+PT_DEV void fetch_node(const KParams &K, const PairLds &L, int cur, int local, int order, float4 &n0, float4 &n1, float4 &n2,
+                       float4 &n3) {
+    if (L.topnodes && (unsigned)local < (unsigned)TOP_NODES) {
+        const float4 *q = L.topnodes + (order * TOP_NODES + local) * 4;
+        n0 = q[0];
+        n1 = q[1];
+        n2 = q[2];
+        n3 = q[3];
+    } else {
+        n0 = K.nodes[cur * 4 + 0];
+        n1 = K.nodes[cur * 4 + 1];
+        n2 = K.nodes[cur * 4 + 2];
+        n3 = K.nodes[cur * 4 + 3];
+    }
+}
+
 // drains the pair queue [0, P): afterwards L.best[r] = min over ray r's pairs of {t bits, order << 24 | slot}
 template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
     LdsStack stk{L.stack + lane};
     int next = 0;
     bool busy = false, active = false, xf = false;
-    int cur = 0, sp = 0, r = 0, oi = 0, sb = -1;
+    int cur = 0, sp = 0, r = 0, oi = 0, sb = -1, rootref = 0;
     float dirScale = 1.0f, tb = T_FAR;
     RayO pr = make_ray(mk3(0.0f), mk3(0.0f, 0.0f, 1.0f));
     TravStats ts;
@@ -449,7 +508,7 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
                 pair_ray_from<GEN>(K, mt, po, pd, dirScale);
                 pr = make_ray(po, pd);
                 xf = (mt.z & 1) != 0;
-                cur = mt.x;
+                cur = rootref = mt.x;
                 sp = 0;
                 tb = T_FAR;
                 sb = -1;
@@ -472,8 +531,8 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);
-                const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
-                             n3 = K.nodes[cur * 4 + 3];
+                float4 n0, n1, n2, n3;
+                fetch_node(K, L, cur, cur - rootref, oi, n0, n1, n2, n3);
                 float tL, tR;
                 const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tb, tL);
                 const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tb, tR);
@@ -606,13 +665,13 @@ PT_DEV float winner_t_local(const KParams &K, int mesh, int slot, f3 o, f3 d) {
 
 PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
     const int P = build_pairs<false, true>(K, L, lane, alive, o, d, T_FAR);
-    __syncthreads();
+    wave_sync();
     const unsigned long long t_q = TS_NOW();
     run_closest_queue<false>(K, L, lane, P, o, d);
     TS_ADDL(8, t_q);
-    __syncthreads();
+    wave_sync();
     const unsigned long long key = L.best[lane];
-    __syncthreads();
+    wave_sync();
     Hit h;
     h.u = h.v = 0.0f;
     if (!alive || key == ~0ull) {
@@ -639,7 +698,7 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
     const float *tmaxv = (const float *)L.best;
     int next = 0;
     bool busy = false;
-    int cur = 0, sp = 0, bot = 0, r = 0; // the lane's stack is entries [bot, sp): thieves take from the bottom
+    int cur = 0, sp = 0, bot = 0, r = 0, oi = 0, rootref = 0; // the lane's stack is entries [bot, sp): thieves take from the bottom
     float tm = 0.0f;
     RayO pr = make_ray(mk3(0.0f), mk3(0.0f, 0.0f, 1.0f));
     TravStats ts;
@@ -666,14 +725,15 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
             if (take) {
                 r = src;
                 if (L.occ[r] == 0u) {
-                    const int4 mt = pair_mesh<GEN>(K, L, r, (int)(e >> 6));
+                    oi = (int)(e >> 6);
+                    const int4 mt = pair_mesh<GEN>(K, L, r, oi);
                     float dirScale;
                     pair_ray_from<GEN>(K, mt, po, pd, dirScale);
                     pr = make_ray(po, pd);
                     tm = tmaxv[r];
                     if (mt.z & 1)
                         tm = tm * dirScale;
-                    cur = mt.x;
+                    cur = rootref = mt.x;
                     sp = bot = 0;
                     busy = true;
                 }
@@ -717,6 +777,7 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
                     pr = npr;
                     tm = ntm;
                     r = nr;
+                    rootref = -(1 << 30); // (a stolen subtree lies below the staged levels: its nodes come from memory)
                     sp = bot = 0;
                     busy = true;
                 }
@@ -738,8 +799,8 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);
-                const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
-                             n3 = K.nodes[cur * 4 + 3];
+                float4 n0, n1, n2, n3;
+                fetch_node(K, L, cur, cur - rootref, oi, n0, n1, n2, n3);
                 float tL, tR;
                 const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tm, tL);
                 const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tm, tR);
@@ -831,13 +892,13 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
 PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
     const int P = build_pairs<true, true>(K, L, lane, alive, o, d, tMax);
     ((float *)L.best)[lane] = tMax;
-    __syncthreads();
+    wave_sync();
     const unsigned long long t_q = TS_NOW();
     run_any_queue<false>(K, L, lane, P, o, d);
     TS_ADDL(11, t_q);
-    __syncthreads();
+    wave_sync();
     const bool occluded = alive && (L.occ[lane] != 0u);
-    __syncthreads();
+    wave_sync();
     return occluded;
 }
 
@@ -1012,10 +1073,10 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
         }
         if (!__builtin_amdgcn_ballot_w64(ns > 0))
             break;
-        __syncthreads();
+        wave_sync();
         const unsigned long long t_q = TS_NOW();
         run_closest_queue<true>(K, L, lane, base, o, d);
-        __syncthreads();
+        wave_sync();
         TS_ADD(8, t_q);
 #ifdef PT_TRAV_STATS
         cyc.c[3] += 1; // fills (closest)
@@ -1034,7 +1095,7 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     best.t_local = best.t;
     if (best.mesh >= 0 && (__float_as_int(K.mesh_recs[best.mesh * MESH_REC_F4 + 1].w) & 1))
@@ -1060,7 +1121,7 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
             t_active = true;
         }
     };
-    __syncthreads();
+    wave_sync();
     for (;;) {
         int base = 0;
         bool any_leaf = false;
@@ -1108,17 +1169,17 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
         }
         if (!any_leaf)
             break;
-        __syncthreads();
+        wave_sync();
         const unsigned long long t_q = TS_NOW();
         run_any_queue<true>(K, L, lane, base, o, d);
-        __syncthreads();
+        wave_sync();
         TS_ADD(8, t_q);
 #ifdef PT_TRAV_STATS
         cyc.c[7] += 1; // fills (any)
 #endif
         if (L.occ[lane] != 0u)
             t_active = need_pop = false; // blocked: nothing more to look for
-        __syncthreads();
+        wave_sync();
     }
     return alive && (L.occ[lane] != 0u);
 }
@@ -1135,14 +1196,38 @@ namespace pt {
 //       2: pair compaction, general BLASes (per-lane traversal, LDS stacks); 3: the same behind a real TLAS, in rounds;
 //       4: as 2 with ONE traversal per iteration: a light sample's shadow ray rides with the next extension ray
 //          (pt_merged.hip.h)
-template <int GEOM, bool FULL, int PMODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, 8))) void path_trace_kernel(const KParams K) {
+//  WG: waves per workgroup.  1 = one 8x8 tile per workgroup.  4 (PMODE 2 only, option lds_nodes): four tiles per
+//      workgroup that share one LDS copy of the mesh heads and of the top TOP_LEVELS levels of every BLAS.
+template <int GEOM, bool FULL, int PMODE, int WG = 1>
+__global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, 8))) void path_trace_kernel(const KParams K) {
     extern __shared__ uint2 lds_raw[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LdsStack stk{lds_raw + lane};
     PairLds PL{};
     constexpr bool MERGED = (PMODE == 4);
-    if (PMODE) {
+    if (WG > 1) {
+        PL = carve_pair_lds_wg((void *)lds_raw, wave, K.pair_meshes, K.stack_entries);
+        const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+        for (int i = threadIdx.x; i < K.pair_meshes; i += 64 * WG) {
+            const int m = K.tlas_mesh_ids[lf.x + i];
+            const MeshHead mh = load_mesh_head(K, m);
+            PL.meshbox[2 * i] = K.mesh_recs[m * MESH_REC_F4 + 0];
+            PL.meshbox[2 * i + 1] = K.mesh_recs[m * MESH_REC_F4 + 1];
+            PL.meshtab[i] = make_int4(mh.root_ref, 0, mh.flags, m);
+        }
+        // the first TOP_NODES nodes of each tree (its top TOP_LEVELS levels: the host numbers them in level order)
+        float4 *top = const_cast<float4 *>(PL.topnodes);
+        for (int i = threadIdx.x; i < K.pair_meshes * TOP_NODES * 4; i += 64 * WG) {
+            const int o = i / (TOP_NODES * 4), k = (i / 4) % TOP_NODES;
+            const int root = __float_as_int(K.mesh_recs[K.tlas_mesh_ids[lf.x + o] * MESH_REC_F4].w);
+            int node = (root >= 0 ? root : 0) + k;
+            node = node < K.n_nodes ? node : (K.n_nodes > 0 ? K.n_nodes - 1 : 0);
+            top[i] = K.n_nodes > 0 ? K.nodes[node * 4 + (i & 3)] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
+        if (K.top_off)
+            PL.topnodes = nullptr;
+    } else if (PMODE) {
         const int staged = (PMODE == 1) ? K.pair_tri_slots : 0;
         PL = carve_pair_lds((void *)lds_raw, staged, PMODE == 3 ? 0 : K.pair_meshes, PMODE >= 2 ? K.stack_entries : 0,
                             PMODE == 3 ? K.tlas_max_leaf : 0, PMODE == 3 ? K.tlas_depth : 0, MERGED ? K.pair_cap : 0);
@@ -1172,7 +1257,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         }
         __syncthreads();
     }
-    const int tile = blockIdx.x;
+    const int tile = WG > 1 ? blockIdx.x * WG + wave : blockIdx.x;
+    if (WG > 1 && tile >= K.n_tiles)
+        return; // (after the workgroup's only barrier)
     const int tx = tile % K.tiles_x, ty = tile / K.tiles_x;
     // Registers are what this kernel runs out of (128 per lane at four waves per SIMD; what does not fit is spilled to
     // scratch, and a reload is a trip to the L2).  State that is only touched when a path starts or ends stays out of
@@ -1547,7 +1634,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         // serialised at the L2 atomic unit: 97 K of them took 1.2 ms per 1080p frame -- hidden behind a
         // 2.7-ms trace, but the whole cost of a light frame (1 spp, 1 bounce: 1.19 ms -> 0.17 ms).
         if (lane == 0) {
-            unsigned long long *w = K.counters + (size_t)blockIdx.x * 3;
+            unsigned long long *w = K.counters + (size_t)tile * 3;
             w[0] += (unsigned long long)a;
             w[1] += (unsigned long long)b;
             w[2] += (unsigned long long)c;

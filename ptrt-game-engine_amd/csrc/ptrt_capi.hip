@@ -155,6 +155,8 @@ struct ptrt_ctx {
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
+    int lds_nodes = 0; // option: PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels (measured slower: DESIGN.md 3.1)
+    int n_nodes = 0;
     int merged = 0; // option: PMODE 4 (one traversal per loop iteration) where PMODE 2 applies; measured equal to PMODE 2 on the showcase frame, 10 % slower on the fluid frame
     bool timed = false;
 };
@@ -341,9 +343,18 @@ int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nod
     const int root = ref_of(0, 0, root_dst, work);
     if (root == INT32_MIN)
         return root;
-    while (!work.empty()) {
-        const Item it = work.back();
-        work.pop_back();
+    // Numbering: the top TOP_LEVELS levels in level order (a tree's first 2^TOP_LEVELS - 1 inner nodes are then its top
+    // levels, which the LDS-staged variant of the trace kernel copies per workgroup), everything below depth first.
+    size_t head = 0;
+    while (head < work.size()) {
+        Item it;
+        if (work[head].depth <= pt::TOP_LEVELS) { // (a node of the top levels: first in, first out)
+            it = work[head];
+            ++head;
+        } else {
+            it = work.back();
+            work.pop_back();
+        }
         if (it.depth > max_depth)
             max_depth = it.depth;
         const ptrt_bvh_node &N = in[it.old_idx];
@@ -506,6 +517,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.pair_split = (c->pair_split && !c->any_transform) ? 1 : 0;
     K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
     K.pair_cap = merged_pair_cap(c);
+    K.n_nodes = c->n_nodes;
     // the compacted leaf phase lists up to 64 x (largest leaf) tests in LEAF_PAIR_BYTES - 512 bytes of LDS: the reference
     // builder's leaves (<= 17 triangles) fit; a scene built with a larger leaf target walks its leaves lane by lane
     K.leaf_pairs = (c->leaf_pairs && (size_t)c->pair_max_leaf * 64 <= (size_t)pt::LEAF_PAIR_BYTES - 512) ? 1 : 0;
@@ -1328,6 +1340,7 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     }
     if (int rc = upload(c, c->d_nodes, R.nodes))
         return rc;
+    c->n_nodes = (int)(R.nodes.size() / 4);
     if (int rc = upload(c, c->d_leaves, R.leaves))
         return rc;
     if (int rc = upload(c, c->d_tris, R.tris))
@@ -1813,7 +1826,20 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         launch_trace<0, 1>(c, K, full, grid, lds);
     else if (pmode == 4)
         launch_trace<1, 4>(c, K, full, grid, lds);
-    else if (pmode == 2)
+    else if (pmode == 2 && c->lds_nodes && c->stack_entries > 0) {
+        // four tiles per workgroup, one LDS copy of the mesh heads and of the BLAS top levels (north star: "BVH nodes
+        // ... staged in LDS")
+        const size_t lds4 = (size_t)c->pair_meshes * (48 + pt::TOP_NODES * 64) +
+                            4 * (512 + (size_t)c->pair_meshes * 128 + 256 + (size_t)c->stack_entries * 512 + pt::LEAF_PAIR_BYTES);
+        if (lds4 > 64 * 1024)
+            return fail(c, PTRT_E_INVALID, "lds_nodes: %zu bytes of LDS per workgroup", lds4);
+        K.n_tiles = grid;
+        K.top_off = c->lds_nodes == 2 ? 1 : 0;
+        if (full)
+            hipLaunchKernelGGL((pt::path_trace_kernel<1, true, 2, 4>), dim3((grid + 3) / 4), dim3(256), lds4, c->stream, K);
+        else
+            hipLaunchKernelGGL((pt::path_trace_kernel<1, false, 2, 4>), dim3((grid + 3) / 4), dim3(256), lds4, c->stream, K);
+    } else if (pmode == 2)
         launch_trace<1, 2>(c, K, full, grid, lds);
     else if (pmode == 3)
         launch_trace<2, 3>(c, K, full, grid, lds);
@@ -2315,7 +2341,9 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         if (value < 0 || value > 64)
             return fail(c, PTRT_E_INVALID, "steal must be 0..64");
         c->steal = (int)value;
-    } else if (n == "merged") // PMODE 4 instead of 2: shadow rays ride with the next extension rays (A/B, tests)
+    } else if (n == "lds_nodes") // PMODE 2 in 4-wave workgroups with the BLAS top levels staged in LDS (A/B, tests)
+        c->lds_nodes = value < 0 ? 0 : (value > 2 ? 2 : (int)value); // (2: the larger workgroups without reading the staged nodes)
+    else if (n == "merged") // PMODE 4 instead of 2: shadow rays ride with the next extension rays (A/B, tests)
         c->merged = value ? 1 : 0;
     else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
         c->leaf_pairs = value ? 1 : 0;

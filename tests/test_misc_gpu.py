@@ -172,7 +172,8 @@ def test_full_size_traversal_variants_agree(P, scene):
     # ("many": 68 meshes behind a real TLAS -- PMODE 3 rounds against plain rounds and the lock-step general walk;
     #  the async / wavefront kernels take single-leaf TLASes only and fall back to the same default there)
     # merged=0: separate closest-hit and any-hit phases (PMODE 2) instead of one traversal per iteration (PMODE 4)
-    for opts in (dict(merged=0), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1)):
+    # lds_nodes=1: four tiles per workgroup sharing an LDS copy of the mesh heads and of the BLAS top levels
+    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):
             for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):

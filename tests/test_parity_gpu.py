@@ -168,7 +168,7 @@ def test_showcase_small(P, O, blue_noise):
     s.close()
 
 
-@pytest.mark.parametrize("merged", [1, 0])
+@pytest.mark.parametrize("merged", [1, 0, 2])
 @pytest.mark.parametrize("fetch_min,leaf_pairs,leaf_min,steal", [(0, 0, 64, 0), (1, 1, 1, 1), (16, 0, 8, 2), (16, 1, 8, 0),
                                                                  (16, 1, 4, 2), (48, 1, 64, 8), (64, 1, 24, 1)])
 def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, leaf_min, steal, merged):
@@ -178,11 +178,13 @@ def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, l
     refill at every threshold, with the leaf phase lane by lane (0) or as compacted (lane, triangle)
     pairs (1), the node loop ending once leaf_min lanes wait at a leaf, and idle lanes stealing shadow-ray subtrees (steal > 0),
     give the oracle's bits -- showcase materials, plus instanced meshes."""
-    if merged and not leaf_pairs:
+    if merged == 1 and not leaf_pairs:
         pytest.skip("the merged traversal always uses the compacted leaf phase")
+    lds_nodes, merged = (1, 0) if merged == 2 else (0, merged)  # (2: the 4-wave workgroups with LDS-staged BLAS top levels)
     s = P.Scene(96, 64)
     P.scenes.showcase(s, segments=12)
     s.set_option("merged", merged)
+    s.set_option("lds_nodes", lds_nodes)
     s.set_option("fetch_min", fetch_min)
     s.set_option("leaf_pairs", leaf_pairs)
     s.set_option("leaf_min", leaf_min)
@@ -198,6 +200,7 @@ def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, l
     s.setInstanceScale(extra, (1.5, 0.7, 1.2))
     s.setBVHLeafTarget(2, 0)
     s.set_option("merged", merged)
+    s.set_option("lds_nodes", lds_nodes)
     s.set_option("fetch_min", fetch_min)
     s.set_option("leaf_pairs", leaf_pairs)
     s.set_option("leaf_min", leaf_min)

@@ -316,7 +316,14 @@ def main():
     for k in ("scene", "width", "height", "spp", "depth"):
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
-    headline = cfg == CONFIGS["cornell1080"] and not (args.denoise or args.bloom or args.preset or args.opt or args.scale != 1.0)
+    plain = not (args.denoise or args.bloom or args.preset or args.opt or args.scale != 1.0 or args.rebuild)
+    headline = cfg == CONFIGS["cornell1080"] and plain
+    # the committed profile (instruction counts, lane occupancy, HBM traffic) that belongs to this very workload, if any
+    profile_key = None
+    if plain:
+        for name, c in list(CONFIGS.items()) + [("many", dict(CONFIGS["cornell1080"], scene="many"))]:
+            if c == cfg:
+                profile_key = name
 
     import torch
     import ptrt_amd as P
@@ -419,7 +426,7 @@ def main():
                    "width": W, "height": H, "spp": spp_used, "max_depth": depth_used,
                    "parallelism": (f"tile{world}-{layout}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
                    "kernel": "path_trace_kernel (megakernel, fused tonemap)"},
-        "roofline": roofline_block(args.config if world == 1 else None, kernel_ms, W * rows0),
+        "roofline": roofline_block(profile_key if world == 1 else None, kernel_ms, W * rows0),
     }
     if c3 is not None:
         out["configs3"] = c3

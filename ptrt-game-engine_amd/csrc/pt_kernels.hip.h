@@ -59,7 +59,8 @@ struct KParams {
     const float4 *tlas_nodes; // child-pair nodes over meshes
     const int2 *tlas_leaves;  // {first index into tlas_mesh_ids, count}
     const int *tlas_mesh_ids;
-    const float4 *tlas_heads; // PMODE 3: per TLAS index (leaf order) 5 float4 of the mesh record: {bmin, root ref}, {bmax, flags}, inverse rows
+    const float4 *tlas_heads; // PMODE 3: per TLAS index (leaf order) TLAS_HEAD_F4 float4, see gather_tlas_heads_kernel
+    float inst_c2;            // PMODE 3: first-pass boxes of instances grow by inst_c2 * (|o.x| + |o.y| + |o.z|) per ray
     const float4 *materials; // 6 float4 per mesh
     const float4 *lights;    // 4 float4 per light
     const float2 *blue_noise; // 64*64
@@ -110,7 +111,7 @@ PT_DEV int global_row(int yl, int y0, int il_period, int il_phase) {
 constexpr int MESH_REC_F4 = 12;
 constexpr int TOP_LEVELS = 3;                    // BLAS levels numbered in level order (ptrt_capi.hip convert_tree)
 constexpr int TOP_NODES = (1 << TOP_LEVELS) - 1;  // ... = the first 7 inner nodes of a tree
-constexpr int TLAS_HEAD_F4 = 5; // head + the three rows of the inverse matrix: what the root-box test of an instance needs
+constexpr int TLAS_HEAD_F4 = 7; // {first-pass box, root}, {.., flags}, the three rows of the inverse matrix, and for an instance its LOCAL box
 constexpr float T_FAR = 1e30f;
 
 PT_DEV f3 tlas_bmin(const KParams &K) {
@@ -695,13 +696,28 @@ __global__ __launch_bounds__(256) void xorwow_init_kernel(uint32_t *rng, int wid
 
 // PMODE 3: the heads of the mesh records in TLAS-leaf order, refreshed before a frame (root boxes move under a GPU
 // refit, the shadow-skip flag with the materials): a lane's leaf is then ONE level of loads away instead of two
-__global__ void gather_tlas_heads_kernel(const float4 *__restrict__ mesh_recs, const int *__restrict__ ids, int n,
-                                         float4 *__restrict__ heads) {
+// Entry j: [0] {box of the FIRST pass, root}, [1] {.., flags}, [2..4] inverse rows, [5], [6] an instance's own head.
+// The first-pass box of an untransformed mesh is its root box (the test is the reference's); that of an instance is a
+// world-space box that provably contains every ray its local-space test can accept (`pre`, host-computed; DESIGN.md
+// 3.10) -- or everything, while the device-side boxes have moved since the host computed it (pre_ok == 0).
+__global__ void gather_tlas_heads_kernel(const float4 *__restrict__ mesh_recs, const float4 *__restrict__ pre,
+                                         const int *__restrict__ ids, int n, float4 *__restrict__ heads, int pre_ok) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n)
         return;
     const int m = ids[j];
-    for (int k = 0; k < TLAS_HEAD_F4; ++k)
+    float4 h0 = mesh_recs[m * MESH_REC_F4 + 0], h1 = mesh_recs[m * MESH_REC_F4 + 1];
+    heads[TLAS_HEAD_F4 * j + 5] = h0;
+    heads[TLAS_HEAD_F4 * j + 6] = h1;
+    if (__float_as_int(h1.w) & 1) {
+        const float4 p0 = pre[2 * m], p1 = pre[2 * m + 1];
+        const float big = 3.0e38f;
+        h0 = make_float4(pre_ok ? p0.x : -big, pre_ok ? p0.y : -big, pre_ok ? p0.z : -big, h0.w);
+        h1 = make_float4(pre_ok ? p1.x : big, pre_ok ? p1.y : big, pre_ok ? p1.z : big, h1.w);
+    }
+    heads[TLAS_HEAD_F4 * j + 0] = h0;
+    heads[TLAS_HEAD_F4 * j + 1] = h1;
+    for (int k = 2; k < 5; ++k)
         heads[TLAS_HEAD_F4 * j + k] = mesh_recs[m * MESH_REC_F4 + k];
 }
 

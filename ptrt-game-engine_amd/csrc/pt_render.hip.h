@@ -919,11 +919,15 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
 template <bool ANY>
 PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, bool has, int2 lf, const RayO &w, float tMax, int slot,
                                int base) {
-    // Pass 1, lock-step over the leaf's entries: untransformed meshes are tested (world ray, ~30 VALU), instances are only
-    // noted.  Pass 2: every lane walks ITS instances (ray into the instance's space: two transforms, a normalisation,
-    // three divisions -- ~160 VALU), one per iteration whatever their positions in the leaf.  In one lock-step loop every
-    // iteration paid for both kinds as soon as one lane's entry was an instance: that loop was most of a PMODE 3 frame.
+    // Pass 1, lock-step over the leaf's entries: ONE world-space slab test per entry.  For an untransformed mesh it is the
+    // reference's root-box test.  For an instance it is a conservative pre-test: its first-pass box (gather_tlas_heads_
+    // kernel), grown by inst_c2 * |o|_1 for this ray, contains every ray the reference's local-space test can accept, so a
+    // miss here is a miss there; a hit only makes the entry a candidate.  Pass 2: every lane runs the reference's test
+    // (ray into the instance's space: two transforms, a normalisation, three divisions, ~160 VALU) on ITS candidates,
+    // one per iteration whatever their positions in the leaf.  (One lock-step loop that transformed the ray for every
+    // instance entry of every lane's leaf was 60 % of a PMODE 3 frame.)
     uint32_t mask = 0u, inst = 0u;
+    const float grow = K.inst_c2 * (__builtin_fabsf(w.o.x) + __builtin_fabsf(w.o.y) + __builtin_fabsf(w.o.z));
     for (int i0 = 0; i0 < K.tlas_max_leaf; i0 += PT_ROOT_CHUNK) {
         float4 ha[PT_ROOT_CHUNK], hb4[PT_ROOT_CHUNK];
 #pragma unroll
@@ -937,11 +941,13 @@ PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, boo
         for (int k = 0; k < PT_ROOT_CHUNK; ++k) {
             const int flags = __float_as_int(hb4[k].w);
             const bool in = has && (i0 + k) < lf.y && !(ANY && (flags & 2));
-            float tE;
-            const bool hb = slab(mk3(ha[k].x, ha[k].y, ha[k].z), mk3(hb4[k].x, hb4[k].y, hb4[k].z), w, ANY ? tMax : T_FAR, tE);
             const bool is_inst = (flags & 1) != 0;
+            const float g = is_inst ? grow : 0.0f; // (x - 0 and x + 0 are x: an untransformed mesh's box is tested as it is)
+            float tE;
+            const bool hb = slab(mk3(ha[k].x - g, ha[k].y - g, ha[k].z - g), mk3(hb4[k].x + g, hb4[k].y + g, hb4[k].z + g), w,
+                                 ANY ? (is_inst ? tMax * 1.0001f + g : tMax) : T_FAR, tE);
             mask |= (in && !is_inst && hb) ? (1u << (i0 + k)) : 0u;
-            inst |= (in && is_inst) ? (1u << (i0 + k)) : 0u;
+            inst |= (in && is_inst && hb) ? (1u << (i0 + k)) : 0u;
         }
         if (!__builtin_amdgcn_ballot_w64(has && i0 + PT_ROOT_CHUNK < lf.y))
             break;
@@ -951,7 +957,7 @@ PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, boo
             const int i = __builtin_ctz(inst);
             inst &= inst - 1u;
             const float4 *rec = K.tlas_heads + TLAS_HEAD_F4 * (lf.x + i);
-            const float4 a = rec[0], b = rec[1];
+            const float4 a = rec[5], b = rec[6];
             float ds, tE;
             const RayO lr = local_ray_rows(rec[2], rec[3], rec[4], w, ds);
             if (slab(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), lr, ANY ? tMax * ds : T_FAR, tE))

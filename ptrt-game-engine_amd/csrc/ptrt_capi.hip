@@ -65,6 +65,9 @@ struct ptrt_ctx {
     int2 *d_leaves = nullptr, *d_tlas_leaves = nullptr;
     int *d_tlas_mesh_ids = nullptr;
     float4 *d_tlas_heads = nullptr; // mesh-record heads in TLAS-leaf order (PMODE 3), gathered before each frame
+    float4 *d_inst_pre = nullptr;   // per mesh: world-space first-pass box of an instance (PMODE 3), host-computed
+    float inst_c2 = 0.0f;           // ... and the per-ray growth factor that goes with it
+    bool inst_pre_ok = false;       // false once device-side boxes have moved (GPU refit / rebuild) since it was computed
     int n_tlas_index = 0;
     std::vector<float4> h_mesh_recs;
     std::vector<unsigned char> h_shadow_skip; // per material: transmission > 0.5
@@ -446,6 +449,7 @@ void free_scene(ptrt_ctx *c) {
     dfree(c->d_tlas_leaves);
     dfree(c->d_tlas_mesh_ids);
     dfree(c->d_tlas_heads);
+    dfree(c->d_inst_pre);
     dfree(c->d_tlas_root_box);
     dfree(c->d_verts);
     dfree(c->d_slot_face);
@@ -501,6 +505,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.tlas_leaves = c->d_tlas_leaves;
     K.tlas_mesh_ids = c->d_tlas_mesh_ids;
     K.tlas_heads = c->d_tlas_heads;
+    K.inst_c2 = c->inst_c2;
     K.materials = c->d_materials;
     K.lights = c->d_lights;
     K.blue_noise = c->d_blue;
@@ -1167,6 +1172,8 @@ int ptrt_reset_rng(ptrt_ctx *c, unsigned long long seed) {
     return PTRT_OK;
 }
 
+int upload_instance_pretests(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count);
+
 int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count, const ptrt_bvh_node *tlas_nodes,
                          int tlas_node_count, const int32_t *tlas_mesh_indices, int tlas_index_count) {
     if (!ctx_live(c))
@@ -1358,7 +1365,97 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     for (const int2 &lf : R.leaves)
         if (lf.y > c->pair_max_leaf)
             c->pair_max_leaf = lf.y;
+    if (int rc = upload_instance_pretests(c, meshes, mesh_count))
+        return rc;
     c->have_geometry = true;
+    return PTRT_OK;
+}
+
+// World-space first-pass boxes of the instances (PMODE 3, pt_render.hip.h build_pairs_general).  The reference tests an
+// instance's root box in ITS space with the ray transformed by the instance's inverse matrix A|t (intersection.cuh:
+// 284-297, 454-463).  Here a ray is first tested against a world-space box W that contains every ray that test can
+// accept: W = the bounding box of A^-1 (corner - t) over the eight corners of the local box, in double precision (A is
+// whatever matrix the caller supplies -- the reference's own mat4::inverse is not always the true inverse, which is
+// why W comes from A and not from the world matrix), grown by C1 + C2 |o|_1 with
+//     C1 = Kc (|A^-1|_F (|t| + |box|) + |W|_inf) + 1e-6,   C2 = Kc (|A^-1|_F |A|_F + 1),   Kc = 1e-4.
+// The fp32 local test can accept a ray only if the exact ray passes within eta <= ~32 * 2^-24 (|A o + t| + |box|) of
+// the local box (five roundings per slab term on quantities of that size, plus the rounded direction over a path of
+// that length); mapped back to world space that is at most |A^-1|_2 eta <= 2e-6 |A^-1|_F (|A|_F |o| + |t| + |box|), and
+// the world test's own rounding is below 1e-6 (|W| + |o|): Kc leaves a factor of 50.  A singular or non-finite A gets
+// an infinite box (every ray is a candidate: the local test decides, as before).
+int upload_instance_pretests(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count) {
+    std::vector<float4> pre((size_t)mesh_count * 2, f4(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f));
+    double c2max = 0.0;
+    const double Kc = 1e-4, BIG = 3.0e38;
+    for (int m = 0; m < mesh_count; ++m) {
+        const ptrt_mesh_desc &M = meshes[m];
+        pre[(size_t)m * 2 + 1] = f4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);
+        if (!M.has_transform || !M.nodes || M.node_count <= 0)
+            continue;
+        double A[3][3], t[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k)
+                A[r][k] = M.inverse[r * 4 + k];
+            t[r] = M.inverse[r * 4 + 3];
+        }
+        const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+        double nA = 0.0, nI = 0.0, I[3][3];
+        bool ok = std::isfinite(det) && std::fabs(det) > 1e-30;
+        if (ok) {
+            I[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det;
+            I[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+            I[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+            I[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
+            I[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
+            I[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+            I[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
+            I[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+            I[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 3; ++k) {
+                    nA += A[r][k] * A[r][k];
+                    nI += I[r][k] * I[r][k];
+                }
+            nA = std::sqrt(nA);
+            nI = std::sqrt(nI);
+        }
+        const ptrt_bvh_node &rn = M.nodes[0];
+        const double lo[3] = {rn.bmin.x, rn.bmin.y, rn.bmin.z}, hi[3] = {rn.bmax.x, rn.bmax.y, rn.bmax.z};
+        double wmin[3] = {BIG, BIG, BIG}, wmax[3] = {-BIG, -BIG, -BIG}, boxn = 0.0, tn = 0.0, wn = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double a = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
+            boxn += a * a;
+            tn += t[k] * t[k];
+        }
+        boxn = std::sqrt(boxn);
+        tn = std::sqrt(tn);
+        for (int corner = 0; ok && corner < 8; ++corner) {
+            const double p[3] = {((corner & 1) ? hi[0] : lo[0]) - t[0], ((corner & 2) ? hi[1] : lo[1]) - t[1],
+                                 ((corner & 4) ? hi[2] : lo[2]) - t[2]};
+            for (int r = 0; r < 3; ++r) {
+                const double x = I[r][0] * p[0] + I[r][1] * p[1] + I[r][2] * p[2];
+                ok = ok && std::isfinite(x);
+                wmin[r] = std::fmin(wmin[r], x);
+                wmax[r] = std::fmax(wmax[r], x);
+                wn = std::fmax(wn, std::fabs(x));
+            }
+        }
+        const double C1 = Kc * (nI * (tn + boxn) + wn) + 1e-6, C2 = Kc * (nI * nA + 1.0);
+        ok = ok && std::isfinite(C1) && std::isfinite(C2) && C1 < 1e30 && C2 < 1e3 && wn < 1e30;
+        if (!ok)
+            continue; // infinite box: every ray is a candidate
+        c2max = std::fmax(c2max, C2);
+        // (outward rounding of the double results to float: one more ulp-sized step than the margin needs)
+        pre[(size_t)m * 2] = f4(std::nextafterf((float)(wmin[0] - C1), -INFINITY), std::nextafterf((float)(wmin[1] - C1), -INFINITY),
+                                 std::nextafterf((float)(wmin[2] - C1), -INFINITY), 0.0f);
+        pre[(size_t)m * 2 + 1] = f4(std::nextafterf((float)(wmax[0] + C1), INFINITY), std::nextafterf((float)(wmax[1] + C1), INFINITY),
+                                     std::nextafterf((float)(wmax[2] + C1), INFINITY), 0.0f);
+    }
+    c->inst_c2 = std::nextafterf((float)c2max, INFINITY);
+    if (int rc = upload(c, c->d_inst_pre, pre))
+        return rc;
+    c->inst_pre_ok = true;
     return PTRT_OK;
 }
 
@@ -1405,6 +1502,9 @@ int ptrt_update_instances(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_co
         return rc;
     drop_graphs(c);
     c->n_instance_updates++;
+    // (the caller's descriptors carry the current root boxes: the Scene mirror refits its host copy with the device's)
+    if (int rc = upload_instance_pretests(c, meshes, mesh_count))
+        return rc;
     return PTRT_OK;
 }
 
@@ -1524,6 +1624,7 @@ int ptrt_refit(ptrt_ctx *c) {
         return fail(c, PTRT_E_NOT_READY, "ptrt_refit: geometry not uploaded");
     if (int rc = set_device(c))
         return rc;
+    c->inst_pre_ok = false; // root boxes move on the device: the instances' first-pass boxes are stale until the next upload
     return run_graphed(c, -1, [c](hipStream_t st) { return enqueue_refit(c, st); });
 }
 
@@ -1532,6 +1633,7 @@ int ptrt_build_bvh(ptrt_ctx *c, int mesh) {
         return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: bad context");
     if (!c->have_geometry)
         return fail(c, PTRT_E_NOT_READY, "ptrt_build_bvh: geometry not uploaded");
+    c->inst_pre_ok = false; // (as in ptrt_refit)
     if (mesh < 0 || mesh >= c->n_meshes)
         return fail(c, PTRT_E_INVALID, "ptrt_build_bvh: no mesh %d", mesh);
     if (!c->mesh_rebuildable[mesh])
@@ -1808,7 +1910,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
     if (pmode == 3) { // (outside the timed kernel: a 136-thread copy)
         hipLaunchKernelGGL(pt::gather_tlas_heads_kernel, dim3((c->n_tlas_index + 63) / 64), dim3(64), 0, c->stream,
-                           c->d_mesh_recs, c->d_tlas_mesh_ids, c->n_tlas_index, c->d_tlas_heads);
+                           c->d_mesh_recs, c->d_inst_pre, c->d_tlas_mesh_ids, c->n_tlas_index, c->d_tlas_heads,
+                           c->inst_pre_ok ? 1 : 0);
         HIP_TRY(c, hipGetLastError());
     }
     const int slot = (int)(c->launches % EV_RING);

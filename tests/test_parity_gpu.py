@@ -103,6 +103,37 @@ def test_real_tlas_many_meshes(P, O, blue_noise, pair_trace, leaf):
     s.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_real_tlas_of_hostile_instances(P, O, blue_noise, seed):
+    """PMODE 3's conservative world-space pre-test of instance root boxes (ptrt_capi.hip upload_instance_pretests) must
+    never reject a ray the reference's local-space test accepts.  56 instances only -- thin slabs, needles, large and tiny
+    scales, every rotation, translations that hit the reference's wrong mat4::inverse (rotation + x translation), some far
+    from the origin, boxes that touch and overlap -- and a camera INSIDE the cloud, so rays start in and next to the boxes;
+    3 frames x 3 spp x 6 bounces against the oracle, every buffer and ray count."""
+    rs = np.random.RandomState(seed)
+    s = P.Scene(80, 56)
+    s.addPlaneXZ(-3.0, 30.0, P.Material((0.5, 0.5, 0.5), 0.7))
+    for k in range(56):
+        mat = P.Material(tuple(rs.uniform(0.2, 0.9, 3)), float(rs.uniform(0.02, 0.9)), float(k % 3 == 0),
+                         transmission=1.0 if k % 9 == 4 else 0.0, ior=1.3)
+        m = s.addSphere(4, mat) if k % 4 == 1 else s.addCube(mat)
+        shape = k % 4
+        scale = {0: rs.uniform(0.3, 1.5, 3), 1: rs.uniform(0.05, 0.2, 3), 2: (rs.uniform(2.0, 5.0), 0.02, rs.uniform(0.5, 2.0)),
+                 3: (0.03, rs.uniform(1.0, 4.0), 0.03)}[shape]
+        far = 40.0 if k % 11 == 7 else 0.0
+        s.setPosition(m, (float(rs.uniform(-4, 4) + far), float(rs.uniform(-2.5, 3)), float(rs.uniform(-9, 1))))
+        s.setRotation(m, tuple(rs.uniform(-3.1, 3.1, 3)))
+        s.setInstanceScale(m, tuple(float(v) for v in scale))
+    s.addPointLight((0, 4, -3), (1.0, 0.95, 0.9), 6.0, 30.0, 0.3)
+    s.addDirectionalLight((-0.3, -1.0, -0.2), (0.9, 0.9, 1.0), 1.5)
+    s.setSkyGradient((0.5, 0.6, 0.9), (0.9, 0.9, 0.9))
+    s.setCamera((0.3, 0.2, -3.5), (0.0, 0.0, -8.0), (0, 1, 0), 75.0)
+    gpu, cpu = render_both(P, O, s, blue_noise, 3, 6, 3)
+    assert_frames_equal(gpu, cpu)
+    assert len(set(gpu[0]["object_id"].tolist())) > 5 and gpu[0]["stats"]["shadow_rays"] > 0
+    s.close()
+
+
 @pytest.mark.parametrize("size", [(1, 1), (7, 3), (8, 8), (9, 17)])
 def test_tiny_and_ragged_frames(P, O, blue_noise, size):
     """Frames smaller than one 8x8 tile and frames whose edges cut tiles."""

@@ -93,3 +93,22 @@ def test_reference_setters_do_not_change_what_a_frame_uses(P):
     s.setPerformancePreset("ultra")  # scene.cuh:1839-1840
     assert s.settings()["spp"] == 128 and s.settings()["depth"] == 32
     s.close()
+
+
+def test_farm_and_interleave_argument_checks_need_no_device(P):
+    ctx, farm = ctypes.c_void_p(), ctypes.c_void_p()
+    # strip `phase` of every `period`: 0 <= phase < period, and the frame must have that strip
+    assert P.lib.ptrt_create_interleaved(64, 64, 3, 3, 0, ctypes.byref(ctx)) == -1 and not ctx.value
+    assert P.lib.ptrt_create_interleaved(64, 20, 3, 8, 0, ctypes.byref(ctx)) == -1   # 20 rows = strips 0..2
+    assert P.lib.ptrt_create_interleaved(0, 64, 0, 2, 0, ctypes.byref(ctx)) == -1
+    assert P.lib.ptrt_farm_create(None, 0, ctypes.byref(farm)) == -1 and not farm.value
+    buf = ctypes.create_string_buffer(256)
+    dead = (ctypes.c_void_p * 1)(ctypes.cast(buf, ctypes.c_void_p))
+    assert P.lib.ptrt_farm_create(dead, 1, ctypes.byref(farm)) == -1 and b"not a live context" in P.lib.ptrt_last_error(None)
+    assert P.lib.ptrt_farm_gather(ctypes.cast(buf, ctypes.c_void_p), None, 0) == -1
+    assert P.lib.ptrt_farm_bands(ctypes.cast(buf, ctypes.c_void_p)) == 0
+    P.lib.ptrt_farm_destroy(ctypes.cast(buf, ctypes.c_void_p))
+    # host-only scenes know their rows without a back end
+    s = P.Scene(64, 52, device=P.HOST_ONLY, interleave=(0, 3))
+    assert s.tile_rows == 8 + 8 + 4  # strips 0, 3, 6 (the last one short)
+    s.close()

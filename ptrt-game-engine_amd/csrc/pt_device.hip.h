@@ -55,11 +55,15 @@ PT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // division.  The oracle divides with the CPU's IEEE divider.
 PT_DEV bool mid_exponent(float x) { return (((__float_as_uint(x) >> 23) & 0xffu) - 67u) < 120u; }
 PT_DEV float rcp_ieee(float y) {
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!mid_exponent(y)) != 0ull, 0))
-        return 1.0f / y;
+    // (the Newton core runs unconditionally and the rare wave with an extreme exponent patches its lanes afterwards:
+    // written as `if (extreme) return 1/y;` first, the compiler laid out three branches in front of the common path)
     const float r0 = __builtin_amdgcn_rcpf(y);
     const float e = fma_(-y, r0, 1.0f);
-    return fma_(e, r0, r0);
+    float r = fma_(e, r0, r0);
+    const bool mid = mid_exponent(y);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!mid) != 0ull, 0))
+        r = mid ? r : 1.0f / y;
+    return r;
 }
 PT_DEV float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 PT_DEV f3 cross(f3 a, f3 b) {

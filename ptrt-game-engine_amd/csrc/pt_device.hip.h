@@ -304,9 +304,25 @@ struct Material {
     float metallic, roughness, transmission, ior, transmissionRoughness, clearcoat, clearcoatRoughness, iridescence,
         iridescenceThickness, sheen;
 };
-PT_DEV Material load_material(const float4 *__restrict__ recs, int id) {
-    const float4 a = recs[id * 6 + 0], b = recs[id * 6 + 1], c = recs[id * 6 + 2], d = recs[id * 6 + 3],
-                 e = recs[id * 6 + 4], f = recs[id * 6 + 5];
+// A load through a pointer KNOWN to point into LDS: a `cond ? lds : global` choice of base otherwise compiles to flat
+// loads of a selected generic pointer.
+typedef float vec4f_t __attribute__((ext_vector_type(4)));
+typedef float vec2f_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const vec4f_t lds_vec4f;
+typedef __attribute__((address_space(3))) const vec2f_t lds_vec2f;
+PT_DEV float4 lds_ld4(const float4 *p, int i) {
+    const vec4f_t v = ((lds_vec4f *)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PT_DEV float2 lds_ld2(const float2 *p, int i) {
+    const vec2f_t v = ((lds_vec2f *)p)[i];
+    return make_float2(v.x, v.y);
+}
+template <bool LDS> PT_DEV float4 ld4(const float4 *p, int i) { return LDS ? lds_ld4(p, i) : p[i]; }
+
+template <bool LDS = false> PT_DEV Material load_material(const float4 *__restrict__ recs, int id) {
+    const float4 a = ld4<LDS>(recs, id * 6 + 0), b = ld4<LDS>(recs, id * 6 + 1), c = ld4<LDS>(recs, id * 6 + 2),
+                 d = ld4<LDS>(recs, id * 6 + 3), e = ld4<LDS>(recs, id * 6 + 4), f = ld4<LDS>(recs, id * 6 + 5);
     Material m;
     m.albedo = mk3(a.x, a.y, a.z);
     m.metallic = a.w;
@@ -838,18 +854,21 @@ PT_DEV bool material_scatter(const Surface &hit, const Material &mat, f3 ray_dir
 }
 
 // ------------------------------------------------------------------ jitter
-PT_DEV void taa_jitter(int frame_index, float &jx, float &jy) {
-    // Halton(2,3) table of 16 as written in the reference (entry 15 repeats x = 0.0625)
-    const int idx = frame_index % 16;
+// Halton(2,3) table of 16 as written in the reference (entry 15 repeats x = 0.0625), minus the 0.5 the caller subtracts
+PT_DEV float2 taa_table_entry(int idx) {
     constexpr float HX[16] = {0.500000f, 0.250000f, 0.750000f, 0.125000f, 0.625000f, 0.375000f, 0.875000f, 0.062500f,
                               0.562500f, 0.312500f, 0.812500f, 0.187500f, 0.687500f, 0.437500f, 0.937500f, 0.062500f};
     constexpr float HY[16] = {0.333333f, 0.666667f, 0.111111f, 0.444444f, 0.777778f, 0.222222f, 0.555556f, 0.888889f,
                               0.037037f, 0.370370f, 0.703704f, 0.148148f, 0.481481f, 0.814815f, 0.259259f, 0.592593f};
-    jx = HX[idx] - 0.5f;
-    jy = HY[idx] - 0.5f;
+    return make_float2(HX[idx] - 0.5f, HY[idx] - 0.5f);
 }
-PT_DEV void blue_noise_jitter(const float2 *__restrict__ table, int x, int y, int frame, float &ou, float &ov) {
-    const float2 val = table[(y & 63) * 64 + (x & 63)];
+PT_DEV void taa_jitter(int frame_index, float &jx, float &jy) {
+    const float2 e = taa_table_entry(frame_index % 16);
+    jx = e.x;
+    jy = e.y;
+}
+// the frame's toroidal shift of the pixel's blue-noise value `val` (= table[(y & 63) * 64 + (x & 63)])
+PT_DEV void blue_noise_shift(float2 val, int frame, float &ou, float &ov) {
     uint32_t hash = (uint32_t)frame * 0x9e3779b9u;
     hash ^= (hash >> 15);
     hash *= 0x85ebca6bu;
@@ -867,6 +886,9 @@ PT_DEV void blue_noise_jitter(const float2 *__restrict__ table, int x, int y, in
         v -= 1.0f;
     ou = u;
     ov = v;
+}
+PT_DEV void blue_noise_jitter(const float2 *__restrict__ table, int x, int y, int frame, float &ou, float &ov) {
+    blue_noise_shift(table[(y & 63) * 64 + (x & 63)], frame, ou, ov);
 }
 
 // ----------------------------------------------------------------- tonemap

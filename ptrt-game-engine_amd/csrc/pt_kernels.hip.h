@@ -82,6 +82,10 @@ struct KParams {
     int n_nodes;        // inner nodes in the arena (the LDS-staged variant clamps its copies to them)
     int top_off;        // WG = 4 variant, A/B: do not read the staged nodes (isolates the cost of the larger workgroups)
     int n_tiles;        // 8x8-pixel tiles of this launch (the 4-wave variant's last workgroup may own fewer than 4)
+    int lds_extra;      // PMODE 1: byte offset in the launch's LDS of the staged shading inputs: the jitter table (16 float2),
+                        // the lanes' blue-noise values (64 float2), then what lds_flags names
+    int lds_flags;      // 0 = nothing staged; bit 2: the jitter inputs are; bit 0: the light records follow (n_lights <=
+                        // LDS_LIGHTS); bit 1: then the material records of the leaf's meshes, by mesh ORDER
     int pair_cap;       // PMODE 4: entries the LDS pair list holds (a multiple of 64, >= 64 * pair_meshes + 64)
     // frame
     Camera cam;
@@ -593,15 +597,11 @@ template <int GEOM> PT_DEV bool any_hit(const KParams &K, bool alive, f3 o, f3 d
 }
 
 // HitInfo fields derived from the winning triangle (intersection.cuh:380-392,465-476)
-PT_DEV Surface make_surface(const KParams &K, const Hit &h, f3 o, f3 d, f3 *local_point, int *face_index) {
-    const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
-    const f3 e1 = mk3(p1.x, p1.y, p1.z), e2 = mk3(p2.x, p2.y, p2.z);
+// HitInfo of a hit (intersection.cuh:382-396, 466-478) from the triangle's edge vectors and its mesh's flags
+PT_DEV Surface make_surface_of(const KParams &K, const Hit &h, f3 e1, f3 e2, int flags, f3 o, f3 d, f3 *local_point) {
     const f3 gn = normalize(cross(e1, e2));
-    const int flags = __float_as_int(K.mesh_recs[h.mesh * MESH_REC_F4 + 1].w);
     Surface s;
     s.t = h.t;
-    if (face_index)
-        *face_index = __float_as_int(p0.w);
     if (!(flags & 1)) {
         s.point = o + h.t * d;
         s.front_face = dot(d, gn) < 0.0f;
@@ -624,14 +624,21 @@ PT_DEV Surface make_surface(const KParams &K, const Hit &h, f3 o, f3 d, f3 *loca
         *local_point = lp;
     return s;
 }
+PT_DEV Surface make_surface(const KParams &K, const Hit &h, f3 o, f3 d, f3 *local_point, int *face_index) {
+    const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
+    const int flags = __float_as_int(K.mesh_recs[h.mesh * MESH_REC_F4 + 1].w);
+    if (face_index)
+        *face_index = __float_as_int(p0.w);
+    return make_surface_of(K, h, mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), flags, o, d, local_point);
+}
 
 struct LightRec {
     f3 position, direction, color;
     int type;
     float intensity, range, inner, outer, radius;
 };
-PT_DEV LightRec load_light(const float4 *__restrict__ L, int i) {
-    const float4 a = L[i * 4 + 0], b = L[i * 4 + 1], c = L[i * 4 + 2], d = L[i * 4 + 3];
+template <bool LDS = false> PT_DEV LightRec load_light(const float4 *__restrict__ L, int i) {
+    const float4 a = ld4<LDS>(L, i * 4 + 0), b = ld4<LDS>(L, i * 4 + 1), c = ld4<LDS>(L, i * 4 + 2), d = ld4<LDS>(L, i * 4 + 3);
     LightRec l;
     l.position = mk3(a.x, a.y, a.z);
     l.type = __float_as_int(a.w);

@@ -55,7 +55,14 @@ struct PairLds {
     uint2 *tstack;            // PMODE 3: [entry][lane] TLAS traversal stack
     unsigned long long *lkey; // 64: {t bits, index in leaf} min per lane
     unsigned char *owner;     // 64 * 17 rounded up: lane of each test
+    // shading inputs staged behind the lists (KParams::lds_extra; one-wave workgroups of PMODE >= 1), else NULL
+    const float2 *jit;        // 16: TAA jitter table
+    const float2 *bn;         // 64: the lanes' blue-noise values
+    const float4 *lights;     // the scene's light records (4 float4 each) when at most LDS_LIGHTS of them
+    const float4 *mats;       // PMODE 1: material records (6 float4) of the leaf's meshes by mesh order
 };
+constexpr int LDS_LIGHTS = 8;
+constexpr int LDS_EXTRA_FIXED = 16 * 8 + 64 * 8; // jitter table + blue-noise values
 constexpr int LEAF_PAIR_BYTES = 512 + 1152;
 // PMODE 3: TLAS leaves a ray may have in one fill of the pair list (a power of two <= 4) and the pairs that end a fill
 #ifndef PT_TLAS_SLOTS
@@ -77,9 +84,9 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     l.best = (unsigned long long *)p;
     p += tlas_leaf ? 512 * TLAS_SLOTS : 512; // (PMODE 3: one minimum per ray and leaf slot)
     l.pairs = (uint32_t *)p;
-    // PMODE 2 and 3 (the modes with a stack) pack them in 16 bits; PMODE 3 holds one TLAS leaf per ray at a time
+    // 16-bit entries {lane, mesh order << 6}; PMODE 3 holds one TLAS leaf per ray at a time
     // (PMODE 4 keeps the pairs of both ray kinds in one list of pair_cap 16-bit entries)
-    p += pair_cap ? (size_t)pair_cap * 2 : tlas_leaf ? ((size_t)tlas_leaf * 64 + TLAS_FILL_TARGET) * 2 : (size_t)meshes * (stack_entries ? 128 : 256);
+    p += pair_cap ? (size_t)pair_cap * 2 : tlas_leaf ? ((size_t)tlas_leaf * 64 + TLAS_FILL_TARGET) * 2 : (size_t)meshes * 128;
     l.ray = (float *)p;
     p += stack_entries ? 0 : 6 * 256; // (PMODE 1 only)
     l.occ = (uint32_t *)p;
@@ -135,6 +142,13 @@ PT_DEV PairLds carve_pair_lds_wg(void *base, int wave, int meshes, int stack_ent
 // calls, pairs, node wave-iterations, node lane-steps, leaf phases, triangle wave-iterations,
 // triangle lane-tests, outer iterations; [16] persistent-loop iterations, [17] live lanes in them.
 __device__ unsigned long long g_trav_stats[32]; // [0..7] closest, [8..15] any-hit, [16..17] loop, [24..31] cycles (CycleAcc)
+// -DPT_MARKS: "; MARK x" comments in the ISA at the phase boundaries of path_trace_kernel (tools/asm_phases.py counts the
+// instructions between them)
+#ifdef PT_MARKS
+#define PT_MARK(x) asm volatile("; MARK " x)
+#else
+#define PT_MARK(x)
+#endif
 #ifdef PT_TRAV_STATS
 struct TravStats {
     unsigned v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -258,10 +272,7 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
         }
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(hb);
         if (hb) {
-            if (SHORT)
-                ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)i << 6));
-            else
-                L.pairs[base + lane_prefix(bal)] = (uint32_t)lane | ((uint32_t)i << 8);
+            ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)i << 6));
         }
         base += __builtin_popcountll(bal);
     }
@@ -297,7 +308,7 @@ template <bool GEN = false> PT_DEV void pair_ray_from(const KParams &K, const in
     }
 }
 
-PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
+PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, int &order) {
     const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
     wave_sync();
     for (int c = 0; c < P; c += 64) {
@@ -312,8 +323,8 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
             ++sh;
         const int p = c + (lane >> sh), sub = lane & ((1 << sh) - 1);
         const bool valid = (lane >> sh) < n;
-        const uint32_t e = L.pairs[valid ? p : 0];
-        const int r = (int)(e & 63u), oi = (int)(e >> 8);
+        const uint32_t e = ((const uint16_t *)L.pairs)[valid ? p : 0];
+        const int r = (int)(e & 63u), oi = (int)(e >> 6);
         const int4 mt = L.meshtab[oi];
         f3 po, pd;
         float dirScale;
@@ -351,6 +362,7 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
     wave_sync(); // the lists are rebuilt by the next trace
     Hit h;
     h.u = h.v = 0.0f;
+    order = 0;
     if (!alive || key == ~0ull) {
         h.t = h.t_local = T_FAR;
         h.mesh = -1;
@@ -358,6 +370,7 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
         return h;
     }
     const int oi = (int)((key >> 16) & 0xffffu), bi = (int)(key & 0xffffu);
+    order = oi;
     const int4 mt = L.meshtab[oi];
     h.t = __uint_as_float((uint32_t)(key >> 32));
     h.mesh = mt.w;
@@ -390,8 +403,8 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
             ++sh;
         const int p = c + (lane >> sh), sub = lane & ((1 << sh) - 1);
         const bool valid = (lane >> sh) < n;
-        const uint32_t e = L.pairs[valid ? p : 0];
-        const int r = (int)(e & 63u), oi = (int)(e >> 8);
+        const uint32_t e = ((const uint16_t *)L.pairs)[valid ? p : 0];
+        const int r = (int)(e & 63u), oi = (int)(e >> 6);
         const int4 mt = L.meshtab[oi];
         f3 po, pd;
         float dirScale;
@@ -1286,6 +1299,41 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
     auto pidx = [&]() { return (size_t)pyl() * K.width + px(); };
     const bool inside = (px() < K.width) && (pyl() < K.rows);
     const size_t npix = K.rng_plane;
+    // PMODE 1 (a scene small enough for its triangles to sit in LDS): what the shading phases would otherwise fetch from
+    // global memory in every iteration is staged too -- the jitter table and the lane's blue-noise value for [A], the light
+    // records for [C], the material records by mesh order; [A], [C], [C2] and [E] then read no global memory.  Worth 2 %
+    // (Cornell 2.27 -> 2.23 ms), and only while the workgroup's LDS stays within 10 KB: the kernel runs 16 waves per CU on
+    // registers, one wave less costs 6.5 % -- which is why the modes whose stacks fill that budget do not stage (measured:
+    // showcase +9 % with 64 bytes too many).
+    constexpr bool STAGED = (PMODE == 1) && (WG == 1);
+    bool lights_lds = false, mats_lds = false, jit_lds = false;
+    if (STAGED && K.lds_flags) { // (0: the launch has no room for them)
+        char *x = (char *)lds_raw + K.lds_extra;
+        float2 *jit = (float2 *)x, *bn = (float2 *)(x + 16 * 8);
+        float4 *lights = (float4 *)(x + LDS_EXTRA_FIXED), *mats = lights + ((K.lds_flags & 1) ? K.n_lights * 4 : 0);
+        if (lane < 16)
+            jit[lane] = taa_table_entry(lane);
+        {
+            const int x0 = px(), y0 = global_row(pyl(), K.y0, K.il_period, K.il_phase);
+            bn[lane] = K.blue_noise[(y0 & 63) * 64 + (x0 & 63)];
+        }
+        lights_lds = (K.lds_flags & 1) != 0;
+        jit_lds = (K.lds_flags & 4) != 0;
+        mats_lds = (PMODE == 1) && (K.lds_flags & 2) != 0;
+        if (lights_lds)
+            for (int i = lane; i < K.n_lights * 4; i += 64)
+                lights[i] = K.lights[i];
+        if (mats_lds) {
+            const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+            for (int i = lane; i < K.pair_meshes * 6; i += 64)
+                mats[i] = K.materials[K.tlas_mesh_ids[lf.x + i / 6] * 6 + i % 6];
+        }
+        PL.jit = jit;
+        PL.bn = bn;
+        PL.lights = lights;
+        PL.mats = mats;
+        __syncthreads();
+    }
 
     Rng rng = {0, 0, 0, 0, 0, 0};
     if (inside) {
@@ -1326,12 +1374,23 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
             }
         }
 #endif
+        PT_MARK("A");
+        const unsigned long long t_pa = TS_NOW();
         // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
         if (live && fresh) {
             const int x = px(), y = global_row(pyl(), K.y0, K.il_period, K.il_phase);
             float tjx, tjy, bnx, bny;
-            taa_jitter(K.frame_count + s, tjx, tjy);
-            blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);
+            if (STAGED && jit_lds) {
+                const float2 e = lds_ld2(PL.jit, (K.frame_count + s) % 16);
+                tjx = e.x;
+                tjy = e.y;
+                int l = lane;
+                asm volatile("" : "+v"(l));
+                blue_noise_shift(lds_ld2(PL.bn, l), K.frame_count + s, bnx, bny);
+            } else {
+                taa_jitter(K.frame_count + s, tjx, tjy);
+                blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);
+            }
             const float jitter_x = tjx + (bnx - 0.5f) * 0.25f;
             const float jitter_y = tjy + (bny - 0.5f) * 0.25f;
             const float u = ((float)x + 0.5f + jitter_x) / (float)K.width;
@@ -1362,8 +1421,12 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
             fresh = false;
         }
 
+        if (PMODE == 1)
+            TS_ADD(8, t_pa);
+        PT_MARK("B");
         // ---- [B] closest hit, all live lanes together (PMODE 4: and the parked shadow rays in the same traversal)
         Hit h;
+        int h_order = 0; // PMODE 1: the hit mesh's place in the leaf (what the staged tables are indexed by)
         if (MERGED) {
             bool blocked = false;
             const unsigned long long t_tr = TS_NOW();
@@ -1380,13 +1443,15 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
             }
         } else {
             const unsigned long long t_tr = TS_NOW();
-            h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd)
+            h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd, h_order)
                 : (PMODE == 2) ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
                 : (PMODE == 3) ? closest_hit_pairs_tlas(K, PL, lane, live, ro, rd, cyc)
                                : closest_hit<GEOM>(K, live, ro, rd, stk);
             TS_ADD(12, t_tr);
         }
 
+        PT_MARK("C");
+        const unsigned long long t_pc = TS_NOW();
         // ---- [C] first half of the shading
         bool end_path = false, shaded = false, want_shadow = false;
         Surface hit;
@@ -1423,7 +1488,14 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
                 end_path = true;
             } else {
                 shaded = true;
-                hit = make_surface(K, h, ro, rd, nullptr, nullptr);
+                if (PMODE == 1 && mats_lds) { // the triangle and the mesh's flags are in LDS
+                    const int ti = h.slot * 3 + h_order * PAIR_PAD;
+                    const float4 p1 = lds_ld4(PL.tris, ti + 1), p2 = lds_ld4(PL.tris, ti + 2);
+                    const int fl = __float_as_int(lds_ld4((const float4 *)PL.meshtab, h_order).z);
+                    hit = make_surface_of(K, h, mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), fl, ro, rd, nullptr);
+                } else {
+                    hit = make_surface(K, h, ro, rd, nullptr, nullptr);
+                }
                 if (bounce == 0 && s == 0) {
                     const size_t idx = pidx();
                     K.normal[idx * 3 + 0] = hit.normal.x;
@@ -1432,7 +1504,14 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
                     K.depth[idx] = hit.t;
                     K.object_id[idx] = h.mesh;
                 }
-                const float4 m0 = K.materials[h.mesh * 6 + 0], m2 = K.materials[h.mesh * 6 + 2];
+                float4 m0, m2;
+                if (mats_lds) {
+                    m0 = lds_ld4(PL.mats, h_order * 6 + 0);
+                    m2 = lds_ld4(PL.mats, h_order * 6 + 2);
+                } else {
+                    m0 = K.materials[h.mesh * 6 + 0];
+                    m2 = K.materials[h.mesh * 6 + 2];
+                }
                 if (!hit.front_face) { // Beer-Lambert on back faces (path_logic.cuh:823-829)
                     const f3 T_unit = mk3(max_(1e-6f, m0.x), max_(1e-6f, m0.y), max_(1e-6f, m0.z));
                     const f3 absorption = mk3(-det_log(T_unit.x), -det_log(T_unit.y), -det_log(T_unit.z));
@@ -1447,7 +1526,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
                     float r = rng_uniform(rng);
                     r = min_(r, 0.99999994f);
                     const int light_index = (int)(r * (float)K.n_lights);
-                    const LightRec light = load_light(K.lights, light_index);
+                    const LightRec light = lights_lds ? load_light<true>(PL.lights, light_index) : load_light(K.lights, light_index);
                     const float pdf_pick = 1.0f / (float)K.n_lights;
                     float attenuation = 1.0f;
                     float light_dist = 1e30f;
@@ -1495,6 +1574,10 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
         }
         n_shadow += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow));
 
+        if (PMODE == 1)
+            TS_ADD(9, t_pc);
+        PT_MARK("C2");
+        const unsigned long long t_pc2 = TS_NOW();
         // ---- [C2] the light sample's value, BEFORE its visibility is known (path_logic.cuh:840-867: bsdf * radiance *
         // attenuation / pdf, soft clamp, MIS weight): `lit_now = throughput * direct * wgt` is what a visible sample adds
         // to `acc`, formed from the same operands in the same order as in the reference and added in the same place, so
@@ -1503,9 +1586,9 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
         bool lit = false;
         f3 lit_now = mk3(0.0f);
         if (want_shadow) {
-            int mi = h.mesh;
+            int mi = mats_lds ? h_order : h.mesh;
             asm volatile("" : "+v"(mi)); // (its own fetch of the material: not 22 registers live across the shadow phase)
-            const Material mat = load_material(K.materials, mi);
+            const Material mat = mats_lds ? load_material<true>(PL.mats, mi) : load_material(K.materials, mi);
             const f3 V = -rd;
             const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
             if (pdf_sample > 0.0f) {
@@ -1520,6 +1603,9 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
             }
         }
 
+        if (PMODE == 1)
+            TS_ADD(10, t_pc2);
+        PT_MARK("D");
         // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas); PMODE 4 parks them instead and
         // walks them with the next extension rays
         const unsigned long long t_sh = TS_NOW();
@@ -1541,9 +1627,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
         }
         TS_ADD(13, t_sh);
 
+        PT_MARK("E");
+        const unsigned long long t_pe = TS_NOW();
         // ---- [E] second half of the shading
         if (shaded) {
-            const Material mat = load_material(K.materials, h.mesh);
+            const Material mat = mats_lds ? load_material<true>(PL.mats, h_order) : load_material(K.materials, h.mesh);
             f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
             bool is_specular = false;
             if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular)) {
@@ -1585,8 +1673,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVE
             ++s;
             fresh = true;
         }
+        if (PMODE == 1)
+            TS_ADD(11, t_pe);
     }
 
+    PT_MARK("Z");
     TS_ADD(14, t_kernel);
     cyc.flush(lane);
     if (inside) {

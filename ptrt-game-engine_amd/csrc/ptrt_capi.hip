@@ -158,6 +158,8 @@ struct ptrt_ctx {
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
+    int lds_pad = 0; // extra bytes of LDS per workgroup (A/B of the occupancy)
+    int stage = 7; // PMODE 1, shading inputs staged in LDS: 0 none, else jitter table + blue noise, | 1 lights, | 2 materials
     int lds_nodes = 0; // option: PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels (measured slower: DESIGN.md 3.1)
     int n_nodes = 0;
     int merged = 0; // option: PMODE 4 (one traversal per loop iteration) where PMODE 2 applies; measured equal to PMODE 2 on the showcase frame, 10 % slower on the fluid frame
@@ -590,7 +592,7 @@ size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
         return ((size_t)c->tlas_max_leaf * 64 + pt::TLAS_FILL_TARGET) * 2 + 512 * pt::TLAS_SLOTS + 256 +
                (size_t)c->stack_entries * 64 * sizeof(uint2) + (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 +
                256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES;
-    const size_t common = (size_t)c->pair_meshes * 48 + (size_t)c->pair_meshes * (pmode == 1 ? 256 : 128) + // (mesh table + staged heads)
+    const size_t common = (size_t)c->pair_meshes * 48 + (size_t)c->pair_meshes * 128 + // (mesh table + staged heads, 16-bit pair entries)
                           (pmode == 1 ? 6 * 256 : 0) + 512 + 256; // (ray planes: PMODE 1 only)
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
@@ -604,7 +606,7 @@ int pair_mode(const ptrt_ctx *c, int geom) {
                    ? 3 : 0;
     if (c->pair_meshes <= 0)
         return 0;
-    if (geom == 0 && c->pair_meshes < 65536 && c->pair_max_leaf < 65536 && pair_lds_bytes(c, 1) <= 40 * 1024)
+    if (geom == 0 && c->pair_meshes < 1024 && c->pair_max_leaf < 65536 && pair_lds_bytes(c, 1) <= 40 * 1024)
         return 1;
     // (PMODE 4's compacted leaf phase is not optional: scenes with leaves beyond its list keep PMODE 2)
     if (geom <= 1 && c->merged && c->leaf_pairs && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) &&
@@ -1914,6 +1916,30 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                            c->inst_pre_ok ? 1 : 0);
         HIP_TRY(c, hipGetLastError());
     }
+    // PMODE 1 stages its shading inputs behind the lists (KParams::lds_extra) while that keeps the workgroup within the
+    // 10 KB of LDS that 16 waves per CU leave each of them
+    size_t lds_main = lds + (size_t)c->lds_pad;
+    if (pmode == 1 && c->stage) {
+        size_t extra = pt::LDS_EXTRA_FIXED;
+        int flags = 4;
+        if ((c->stage & 1) && c->n_lights > 0 && c->n_lights <= pt::LDS_LIGHTS) {
+            flags |= 1;
+            extra += (size_t)c->n_lights * 64;
+        }
+        if ((c->stage & 2) && c->pair_meshes <= 42) { // (96 B per mesh: up to 4 KB)
+            flags |= 2;
+            extra += (size_t)c->pair_meshes * 96;
+        }
+        const size_t at = (lds + 15) & ~(size_t)15;
+        if (at + extra + (size_t)c->lds_pad <= 10240) {
+            K.lds_extra = (int)at;
+            K.lds_flags = flags;
+            lds_main = at + extra + (size_t)c->lds_pad;
+        }
+    }
+    if (c->launches == 0 && getenv("PTRT_DEBUG_LDS"))
+        fprintf(stderr, "ptrt: pmode %d, %d meshes in the leaf, %d triangle slots, stack %d, LDS %zu + %zu bytes per workgroup\n", pmode,
+                c->pair_meshes, c->pair_tri_slots, c->stack_entries, lds, lds_main - lds);
     const int slot = (int)(c->launches % EV_RING);
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
     c->last_mode = 0;
@@ -1926,9 +1952,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
             return rc;
         c->last_mode = 1;
     } else if (pmode == 1)
-        launch_trace<0, 1>(c, K, full, grid, lds);
+        launch_trace<0, 1>(c, K, full, grid, lds_main);
     else if (pmode == 4)
-        launch_trace<1, 4>(c, K, full, grid, lds);
+        launch_trace<1, 4>(c, K, full, grid, lds_main);
     else if (pmode == 2 && c->lds_nodes && c->stack_entries > 0) {
         // four tiles per workgroup, one LDS copy of the mesh heads and of the BLAS top levels (north star: "BVH nodes
         // ... staged in LDS")
@@ -1943,9 +1969,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         else
             hipLaunchKernelGGL((pt::path_trace_kernel<1, false, 2, 4>), dim3((grid + 3) / 4), dim3(256), lds4, c->stream, K);
     } else if (pmode == 2)
-        launch_trace<1, 2>(c, K, full, grid, lds);
+        launch_trace<1, 2>(c, K, full, grid, lds_main);
     else if (pmode == 3)
-        launch_trace<2, 3>(c, K, full, grid, lds);
+        launch_trace<2, 3>(c, K, full, grid, lds_main);
     else if (geom == 0)
         launch_trace<0, 0>(c, K, full, grid, lds);
     else if (geom == 1)
@@ -2450,6 +2476,13 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->merged = value ? 1 : 0;
     else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
         c->leaf_pairs = value ? 1 : 0;
+    else if (n == "lds_pad") { // extra bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy, tests)
+        if (value < 0 || value > 32768)
+            return fail(c, PTRT_E_INVALID, "lds_pad must be 0..32768");
+        c->lds_pad = (int)value;
+    }
+    else if (n == "stage") // PMODE 1: shading inputs staged in LDS (0 none; else jitter inputs, | 1 lights, | 2 materials; A/B, tests)
+        c->stage = (int)(value & 7);
     else if (n == "pair_split") // PMODE 1: 0 = one lane per pair also in batches that do not fill the wave (A/B, tests)
         c->pair_split = value ? 1 : 0;
     else if (n == "async_lanes") // 1: persistent megakernel with asynchronous lanes for single-leaf-TLAS scenes

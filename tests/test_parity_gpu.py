@@ -84,6 +84,26 @@ def test_cornell_one_lane_per_pair(P, O, blue_noise):
     s.close()
 
 
+@pytest.mark.parametrize("stage,lights,pad", [(0, 1, 0), (4, 1, 0), (5, 3, 0), (6, 8, 0), (7, 8, 0), (7, 11, 0), (7, 3, 4096)])
+def test_cornell_staged_shading_inputs(P, O, blue_noise, stage, lights, pad):
+    """PMODE 1 keeps its shading inputs in LDS (jitter table, blue-noise values, light and material records): every subset,
+    more lights than fit (11 > 8: they stay in global memory), and a launch whose LDS has no room (nothing staged)."""
+    s = P.Scene(88, 72)
+    P.scenes.cornell(s)
+    for i in range(1, lights):  # (the scene has one light already)
+        if i % 3 == 0:
+            s.addSpotLight((0.3 * i - 1.0, 1.6, 0.2 * i - 1.0), (0.1, -1.0, 0.05 * i), (1.0, 0.8, 0.6), 6.0, 0.6, 0.9, 50.0, 0.05)
+        elif i % 3 == 1:
+            s.addPointLight((0.2 * i - 1.0, 1.2, -0.5 + 0.1 * i), (0.5, 0.7, 1.0), 3.0, 30.0, 0.1 if i % 2 else 0.0)
+        else:
+            s.addDirectionalLight((0.3, -1.0, 0.2 * i), (0.9, 0.9, 0.8), 0.7)
+    s.set_option("stage", stage)
+    s.set_option("lds_pad", pad)
+    gpu, cpu = render_both(P, O, s, blue_noise, 3, 4, 2)
+    assert_frames_equal(gpu, cpu)
+    s.close()
+
+
 def _many_meshes(P, s, n=40, instanced=True):
     P.scenes.many(s, n, instanced)
 

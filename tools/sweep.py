@@ -21,7 +21,7 @@ s.setMaxBounceDepth(4)
 s.initBlueNoise()
 s.uploadToGPU()
 buf = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
-defaults = dict(merged=0, lds_nodes=0, fetch_min=16, leaf_min=8, steal=1, leaf_pairs=1, pair_trace=1)
+defaults = dict(merged=0, lds_nodes=0, fetch_min=16, leaf_min=8, steal=1, leaf_pairs=1, pair_trace=1, stage=7, lds_pad=0)
 for spec in sys.argv[3:] or [""]:
     opts = dict(defaults)
     for kv in filter(None, spec.split(",")):

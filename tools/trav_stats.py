@@ -60,8 +60,12 @@ if cy[14]:  # instrumented build: where a wave's cycles go (s_memtime, summed ov
     pct = lambda k: 100.0 * cy[k] / tot
     print(f"wave cycles {tot:.4g}: closest-hit (or merged) trace {pct(12):.1f} %, shadow trace {pct(13):.1f} %, "
           f"everything else {100.0 - pct(12) - pct(13):.1f} %")
-    print(f"   inside: queue runs {pct(8):.1f} %, closest node loops {pct(9):.1f} %, closest leaf blocks {pct(10):.1f} %, "
-          f"any-hit queue runs {pct(11):.1f} %")
+    if scene == "cornell":  # PMODE 1 has no queues: its build spends those slots on the shading phases
+        print(f"   shading: [A] regenerate {pct(8):.1f} %, [C] surface + light sample {pct(9):.1f} %, [C2] BSDF of the light sample "
+              f"{pct(10):.1f} %, [E] scatter {pct(11):.1f} %")
+    else:
+        print(f"   inside: queue runs {pct(8):.1f} %, closest node loops {pct(9):.1f} %, closest leaf blocks {pct(10):.1f} %, "
+              f"any-hit queue runs {pct(11):.1f} %")
     if v[2] and v[5]:
         print(f"   per closest node wave-iteration {cy[9] / v[2]:.0f} units, per closest triangle wave-iteration {cy[10] / v[5]:.0f} units")
 print(f"persistent loop: {v[16]} iterations, live lanes {100.0 * v[17] / max(1, v[16] * 64):.1f} %")

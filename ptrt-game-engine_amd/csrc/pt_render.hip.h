@@ -46,7 +46,6 @@ struct PairLds {
     float4 *meshbox;          // per mesh order: {bmin, root ref}, {bmax, flags}: the mesh record's head, staged once
     const float4 *topnodes;   // WG = 4 variant: the first TOP_NODES nodes of every mesh of the leaf, [order][node][4], or NULL
     uint32_t *pairs;          // 64 * pair_meshes
-    float *ray;               // 6 planes of 64
     unsigned long long *best; // 64
     uint32_t *occ;            // 64
     uint2 *stack;             // PMODE 2: [entry][lane] BLAS traversal stack
@@ -87,8 +86,6 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     // 16-bit entries {lane, mesh order << 6}; PMODE 3 holds one TLAS leaf per ray at a time
     // (PMODE 4 keeps the pairs of both ray kinds in one list of pair_cap 16-bit entries)
     p += pair_cap ? (size_t)pair_cap * 2 : tlas_leaf ? ((size_t)tlas_leaf * 64 + TLAS_FILL_TARGET) * 2 : (size_t)meshes * 128;
-    l.ray = (float *)p;
-    p += stack_entries ? 0 : 6 * 256; // (PMODE 1 only)
     l.occ = (uint32_t *)p;
     p += 256;
     l.stack = (uint2 *)p;
@@ -131,7 +128,6 @@ PT_DEV PairLds carve_pair_lds_wg(void *base, int wave, int meshes, int stack_ent
     p += 512;
     l.owner = (unsigned char *)p;
     l.tris = nullptr;
-    l.ray = nullptr;
     l.tstack = nullptr;
     l.leafx = nullptr;
     return l;
@@ -237,19 +233,11 @@ PT_DEV void leaf_prefix(int cnt, int &start, int &total) {
 }
 
 // step 1: root-box tests + ballot/prefix-sum compaction into the LDS pair list
-template <bool ANY, bool SHORT = false>
+template <bool ANY>
 PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
     const RayO w = make_ray(o, d);
     float tE;
     alive = alive && slab(tlas_bmin(K), tlas_bmax(K), w, ANY ? tMax : T_FAR, tE);
-    if (!SHORT) { // PMODE 1 hands the rays over through LDS; the queue modes take them from the owner lane's registers
-        L.ray[0 * 64 + lane] = o.x;
-        L.ray[1 * 64 + lane] = o.y;
-        L.ray[2 * 64 + lane] = o.z;
-        L.ray[3 * 64 + lane] = d.x;
-        L.ray[4 * 64 + lane] = d.y;
-        L.ray[5 * 64 + lane] = d.z;
-    }
     if (ANY)
         L.occ[lane] = 0u;
     else
@@ -279,22 +267,8 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
     return base;
 }
 
-// ray of a pair in the mesh's space (tri_test needs origin and direction only)
-PT_DEV void pair_ray(const KParams &K, const PairLds &L, int r, const int4 mt, f3 &o, f3 &d, float &dirScale) {
-    o = mk3(L.ray[r], L.ray[64 + r], L.ray[128 + r]);
-    d = mk3(L.ray[192 + r], L.ray[256 + r], L.ray[320 + r]);
-    dirScale = 1.0f;
-    if (mt.z & 1) {
-        const float4 *rec = K.mesh_recs + mt.w * MESH_REC_F4;
-        const f3 lo = xform_point(rec[2], rec[3], rec[4], o);
-        const f3 ld = xform_dir(rec[2], rec[3], rec[4], d);
-        dirScale = length(ld);
-        o = lo;
-        d = normalize(ld);
-    }
-}
-
-// the same from a world ray already in registers (queue modes: fetched from the owner lane by ds_bpermute)
+// ray of a pair in the mesh's space (tri_test needs origin and direction only), from the world ray -- fetched from the
+// owner lane's registers by ds_bpermute: no ray planes in LDS
 // (`GEN`: mt.w is a TLAS index and the rows come from the leaf-order copy; else it is a mesh id)
 template <bool GEN = false> PT_DEV void pair_ray_from(const KParams &K, const int4 mt, f3 &o, f3 &d, float &dirScale) {
     dirScale = 1.0f;
@@ -326,9 +300,11 @@ PT_DEV Hit closest_hit_pairs(const KParams &K, const PairLds &L, int lane, bool 
         const uint32_t e = ((const uint16_t *)L.pairs)[valid ? p : 0];
         const int r = (int)(e & 63u), oi = (int)(e >> 6);
         const int4 mt = L.meshtab[oi];
-        f3 po, pd;
+        // (every lane executes the shuffles: a source lane must be active for ds_bpermute)
+        f3 po = mk3(__shfl(o.x, r), __shfl(o.y, r), __shfl(o.z, r));
+        f3 pd = mk3(__shfl(d.x, r), __shfl(d.y, r), __shfl(d.z, r));
         float dirScale;
-        pair_ray(K, L, r, mt, po, pd, dirScale);
+        pair_ray_from<false>(K, mt, po, pd, dirScale);
         RayO pr;
         pr.o = po;
         pr.d = pd;
@@ -406,9 +382,11 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
         const uint32_t e = ((const uint16_t *)L.pairs)[valid ? p : 0];
         const int r = (int)(e & 63u), oi = (int)(e >> 6);
         const int4 mt = L.meshtab[oi];
-        f3 po, pd;
+        // (every lane executes the shuffles: a source lane must be active for ds_bpermute)
+        f3 po = mk3(__shfl(o.x, r), __shfl(o.y, r), __shfl(o.z, r));
+        f3 pd = mk3(__shfl(d.x, r), __shfl(d.y, r), __shfl(d.z, r));
         float dirScale;
-        pair_ray(K, L, r, mt, po, pd, dirScale);
+        pair_ray_from<false>(K, mt, po, pd, dirScale);
         RayO pr;
         pr.o = po;
         pr.d = pd;
@@ -677,7 +655,7 @@ PT_DEV float winner_t_local(const KParams &K, int mesh, int slot, f3 o, f3 d) {
 }
 
 PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
-    const int P = build_pairs<false, true>(K, L, lane, alive, o, d, T_FAR);
+    const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
     wave_sync();
     const unsigned long long t_q = TS_NOW();
     run_closest_queue<false>(K, L, lane, P, o, d);
@@ -903,7 +881,7 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
 }
 
 PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
-    const int P = build_pairs<true, true>(K, L, lane, alive, o, d, tMax);
+    const int P = build_pairs<true>(K, L, lane, alive, o, d, tMax);
     ((float *)L.best)[lane] = tMax;
     wave_sync();
     const unsigned long long t_q = TS_NOW();
@@ -1211,6 +1189,19 @@ namespace pt {
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 3
 #endif
+// Waves per SIMD a variant is built for (= its register budget: 512 / waves, in steps of 8).  PMODE 1 with the simple
+// materials -- a whole small scene in 7.5 KB of LDS, no traversal stacks -- runs five (96 VGPRs; the Cornell kernel then
+// spills 22 registers, 88 B per lane, and is still 4 % faster: 2.233 -> 2.150 ms).  Its FULL variant would spill 168 B per
+// lane (measured on Cornell with force_full: 2.29 -> 2.69 ms) and stays at four; the modes with per-lane stacks need their
+// 10 KB of LDS per wave, which caps a CU at 16 waves whatever the registers (and at 96 VGPRs they spill 83-120 registers).
+#ifndef PT_WAVES_PMODE1
+#define PT_WAVES_PMODE1 5
+#endif
+constexpr int waves_per_simd(int pmode, bool full) { return (pmode == 1 && !full) ? PT_WAVES_PMODE1 : PT_WAVES_PER_EU; }
+// LDS a one-wave workgroup may use without lowering that occupancy: a CU has 160 KB, allocated in 1280-byte granules
+// (measured: Cornell at 7,680 B runs 20 waves per CU, at 7,744 B visibly fewer; showcase at 10,192 B 16, at 10,384 B fewer)
+constexpr int LDS_GRANULE = 1280;
+constexpr int lds_per_wave(int pmode, bool full) { return 160 * 1024 / (4 * waves_per_simd(pmode, full)) / LDS_GRANULE * LDS_GRANULE; }
 // PMODE 0: lock-step mesh loop; 1: pair compaction, single-leaf BLASes (triangles staged in LDS);
 //       2: pair compaction, general BLASes (per-lane traversal, LDS stacks); 3: the same behind a real TLAS, in rounds;
 //       4: as 2 with ONE traversal per iteration: a light sample's shadow ray rides with the next extension ray
@@ -1218,7 +1209,7 @@ namespace pt {
 //  WG: waves per workgroup.  1 = one 8x8 tile per workgroup.  4 (PMODE 2 only, option lds_nodes): four tiles per
 //      workgroup that share one LDS copy of the mesh heads and of the top TOP_LEVELS levels of every BLAS.
 template <int GEOM, bool FULL, int PMODE, int WG = 1>
-__global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, 8))) void path_trace_kernel(const KParams K) {
+__global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_per_simd(PMODE, FULL), 8))) void path_trace_kernel(const KParams K) {
     extern __shared__ uint2 lds_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LdsStack stk{lds_raw + lane};

@@ -593,7 +593,7 @@ size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
                (size_t)c->stack_entries * 64 * sizeof(uint2) + (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 +
                256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES;
     const size_t common = (size_t)c->pair_meshes * 48 + (size_t)c->pair_meshes * 128 + // (mesh table + staged heads, 16-bit pair entries)
-                          (pmode == 1 ? 6 * 256 : 0) + 512 + 256; // (ray planes: PMODE 1 only)
+                          512 + 256;
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
 }
@@ -1917,7 +1917,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         HIP_TRY(c, hipGetLastError());
     }
     // PMODE 1 stages its shading inputs behind the lists (KParams::lds_extra) while that keeps the workgroup within the
-    // 10 KB of LDS that 16 waves per CU leave each of them
+    // LDS that the occupancy its kernel is built for leaves each wave (pt::lds_per_wave)
     size_t lds_main = lds + (size_t)c->lds_pad;
     if (pmode == 1 && c->stage) {
         size_t extra = pt::LDS_EXTRA_FIXED;
@@ -1931,7 +1931,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
             extra += (size_t)c->pair_meshes * 96;
         }
         const size_t at = (lds + 15) & ~(size_t)15;
-        if (at + extra + (size_t)c->lds_pad <= 10240) {
+        if (at + extra + (size_t)c->lds_pad <= (size_t)pt::lds_per_wave(1, full)) {
             K.lds_extra = (int)at;
             K.lds_flags = flags;
             lds_main = at + extra + (size_t)c->lds_pad;

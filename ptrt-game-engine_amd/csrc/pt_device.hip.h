@@ -314,6 +314,8 @@ PT_DEV float4 lds_ld4(const float4 *p, int i) {
     const vec4f_t v = ((lds_vec4f *)p)[i];
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef __attribute__((address_space(3))) const float lds_f32;
+PT_DEV float lds_ld1(const float *p, int i) { return ((lds_f32 *)p)[i]; }
 PT_DEV float2 lds_ld2(const float2 *p, int i) {
     const vec2f_t v = ((lds_vec2f *)p)[i];
     return make_float2(v.x, v.y);

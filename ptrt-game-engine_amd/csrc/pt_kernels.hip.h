@@ -55,7 +55,8 @@ struct KParams {
     const float4 *mesh_recs;  // 12 float4 per mesh
     const float4 *nodes;      // 4 float4 per inner node (child pair)
     const int2 *leaves;       // {first tri slot, count}
-    const float4 *tris;       // 3 float4 per leaf slot
+    const float4 *tris;       // 3 float4 per leaf slot: {v0, e1, e2}; the three w hold the geometric normal (tri_normals_kernel)
+    const int4 *slot_face;    // per leaf slot: global vertex indices + face index
     const float4 *tlas_nodes; // child-pair nodes over meshes
     const int2 *tlas_leaves;  // {first index into tlas_mesh_ids, count}
     const int *tlas_mesh_ids;
@@ -597,9 +598,22 @@ template <int GEOM> PT_DEV bool any_hit(const KParams &K, bool alive, f3 o, f3 d
 }
 
 // HitInfo fields derived from the winning triangle (intersection.cuh:380-392,465-476)
-// HitInfo of a hit (intersection.cuh:382-396, 466-478) from the triangle's edge vectors and its mesh's flags
-PT_DEV Surface make_surface_of(const KParams &K, const Hit &h, f3 e1, f3 e2, int flags, f3 o, f3 d, f3 *local_point) {
-    const f3 gn = normalize(cross(e1, e2));
+// The geometric normal of a packet, normalize(cross(e1, e2)) (intersection.cuh:386, 470), is a property of the triangle:
+// computed once per (re)packing by the one function below and kept in the packets' three spare w words, instead of a cross
+// product, a square root and three divisions (~100 VALU) in every shading iteration.
+PT_DEV f3 packet_normal(float4 p1, float4 p2) { return normalize(cross(mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z))); }
+__global__ void tri_normals_kernel(float4 *__restrict__ tris, int n_slots) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots)
+        return;
+    const f3 gn = packet_normal(tris[s * 3 + 1], tris[s * 3 + 2]);
+    tris[s * 3 + 0].w = gn.x;
+    tris[s * 3 + 1].w = gn.y;
+    tris[s * 3 + 2].w = gn.z;
+}
+
+// HitInfo of a hit (intersection.cuh:382-396, 466-478) from the triangle's geometric normal and its mesh's flags
+PT_DEV Surface make_surface_of(const KParams &K, const Hit &h, f3 gn, int flags, f3 o, f3 d, f3 *local_point) {
     Surface s;
     s.t = h.t;
     if (!(flags & 1)) {
@@ -625,11 +639,12 @@ PT_DEV Surface make_surface_of(const KParams &K, const Hit &h, f3 e1, f3 e2, int
     return s;
 }
 PT_DEV Surface make_surface(const KParams &K, const Hit &h, f3 o, f3 d, f3 *local_point, int *face_index) {
-    const float4 p0 = K.tris[h.slot * 3 + 0], p1 = K.tris[h.slot * 3 + 1], p2 = K.tris[h.slot * 3 + 2];
+    const float *w = (const float *)(K.tris + h.slot * 3);
+    const f3 gn = mk3(w[3], w[7], w[11]);
     const int flags = __float_as_int(K.mesh_recs[h.mesh * MESH_REC_F4 + 1].w);
     if (face_index)
-        *face_index = __float_as_int(p0.w);
-    return make_surface_of(K, h, mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), flags, o, d, local_point);
+        *face_index = K.slot_face[h.slot].w;
+    return make_surface_of(K, h, gn, flags, o, d, local_point);
 }
 
 struct LightRec {

@@ -4,7 +4,7 @@
 // Replaces, for the per-frame part, the reference's Mesh::upload realloc + CPU Mesh::buildBVH +
 // Mesh::uploadBVH + TLAS rebuild (mesh.cuh:330-346,403-516; scene.cuh:656-733) -- the reference
 // has no refit.  Four small steps on the context's stream, no host synchronisation:
-//   1. repack_tris_kernel    triangle packets {v0|face, e1, e2} from the new vertices
+//   1. repack_tris_kernel    triangle packets {v0, e1, e2 | geometric normal} from the new vertices
 //   2. refit_leaves_kernel   leaf boxes = min/max over the leaf's triangle vertices, stored into
 //                            the parent's child-pair slot (or the mesh root box)
 //   3. refit_level_kernel    one launch per WIDE tree level (> 2048 nodes), deepest first: node
@@ -31,9 +31,11 @@ __global__ void repack_tris_kernel(const float *__restrict__ verts, const int4 *
     const float ax = verts[f.x * 3], ay = verts[f.x * 3 + 1], az = verts[f.x * 3 + 2];
     const float bx = verts[f.y * 3], by = verts[f.y * 3 + 1], bz = verts[f.y * 3 + 2];
     const float cx = verts[f.z * 3], cy = verts[f.z * 3 + 1], cz = verts[f.z * 3 + 2];
-    tris[s * 3 + 0] = make_float4(ax, ay, az, __int_as_float(f.w));
-    tris[s * 3 + 1] = make_float4(bx - ax, by - ay, bz - az, 0.0f);
-    tris[s * 3 + 2] = make_float4(cx - ax, cy - ay, cz - az, 0.0f);
+    const float4 p1 = make_float4(bx - ax, by - ay, bz - az, 0.0f), p2 = make_float4(cx - ax, cy - ay, cz - az, 0.0f);
+    const f3 gn = packet_normal(p1, p2); // (the packets' w words: see tri_normals_kernel)
+    tris[s * 3 + 0] = make_float4(ax, ay, az, gn.x);
+    tris[s * 3 + 1] = make_float4(p1.x, p1.y, p1.z, gn.y);
+    tris[s * 3 + 2] = make_float4(p2.x, p2.y, p2.z, gn.z);
 }
 
 // box -> its storage: dst >= 0: child slot (dst & 1) of inner node (dst >> 1); dst < 0: root box of mesh -dst-1

@@ -1480,10 +1480,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             } else {
                 shaded = true;
                 if (PMODE == 1 && mats_lds) { // the triangle and the mesh's flags are in LDS
-                    const int ti = h.slot * 3 + h_order * PAIR_PAD;
-                    const float4 p1 = lds_ld4(PL.tris, ti + 1), p2 = lds_ld4(PL.tris, ti + 2);
-                    const int fl = __float_as_int(lds_ld4((const float4 *)PL.meshtab, h_order).z);
-                    hit = make_surface_of(K, h, mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), fl, ro, rd, nullptr);
+                    const int ti = (h.slot * 3 + h_order * PAIR_PAD) * 4;
+                    const f3 gn = mk3(lds_ld1((const float *)PL.tris, ti + 3), lds_ld1((const float *)PL.tris, ti + 7),
+                                      lds_ld1((const float *)PL.tris, ti + 11));
+                    const int fl = __float_as_int(lds_ld1((const float *)PL.meshtab, h_order * 4 + 2));
+                    hit = make_surface_of(K, h, gn, fl, ro, rd, nullptr);
                 } else {
                     hit = make_surface(K, h, ro, rd, nullptr, nullptr);
                 }

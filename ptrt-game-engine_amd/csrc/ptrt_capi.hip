@@ -503,6 +503,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.nodes = c->d_nodes;
     K.leaves = c->d_leaves;
     K.tris = c->d_tris;
+    K.slot_face = c->d_slot_face;
     K.tlas_nodes = c->d_tlas_nodes;
     K.tlas_leaves = c->d_tlas_leaves;
     K.tlas_mesh_ids = c->d_tlas_mesh_ids;
@@ -1246,7 +1247,7 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
                 const ptrt_vec3 &a = M.verts[t.v0], &b = M.verts[t.v1], &d = M.verts[t.v2];
                 // e1 = v1 - v0, e2 = v2 - v0: the same fp32 subtractions the reference performs per
                 // test (intersection.cuh:224-225), done once here
-                R.tris.push_back(f4(a.x, a.y, a.z, as_f(fidx)));
+                R.tris.push_back(f4(a.x, a.y, a.z, 0.0f)); // (the w words: tri_normals_kernel, below)
                 R.tris.push_back(f4(b.x - a.x, b.y - a.y, b.z - a.z, 0.0f));
                 R.tris.push_back(f4(d.x - a.x, d.y - a.y, d.z - a.z, 0.0f));
             }
@@ -1354,6 +1355,11 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
         return rc;
     if (int rc = upload(c, c->d_tris, R.tris))
         return rc;
+    if (!R.tris.empty()) { // the packets' geometric normals, by the same device code a repack uses (pt::packet_normal)
+        const int n = (int)(R.tris.size() / 3);
+        hipLaunchKernelGGL(pt::tri_normals_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_tris, n);
+        HIP_TRY(c, hipGetLastError());
+    }
     if (int rc = upload_tlas(c, mesh_count, tlas_nodes, tlas_node_count, tlas_mesh_indices, tlas_index_count, false))
         return rc;
     c->n_geometry_uploads++;

@@ -37,7 +37,7 @@ PT_DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 PT_DEV f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 PT_DEV f3 operator*(f3 a, float t) { return f3{a.x * t, a.y * t, a.z * t}; }
 PT_DEV f3 operator*(float t, f3 a) { return f3{a.x * t, a.y * t, a.z * t}; }
-PT_DEV f3 operator/(f3 a, float t) { return f3{a.x / t, a.y / t, a.z / t}; }
+PT_DEV f3 operator/(f3 a, float t); // (three quotients by one divisor: div3, below)
 PT_DEV f3 operator/(f3 a, f3 b) { return f3{a.x / b.x, a.y / b.y, a.z / b.z}; }
 PT_DEV f3 operator+(f3 a, float t) { return f3{a.x + t, a.y + t, a.z + t}; }
 PT_DEV f3 operator-(f3 a, float t) { return f3{a.x - t, a.y - t, a.z - t}; }
@@ -65,6 +65,46 @@ PT_DEV float rcp_ieee(float y) {
         r = mid ? r : 1.0f / y;
     return r;
 }
+// v / t for a vector: the reference divides component by component (vec3.cuh:54-56), so three IEEE divisions share their
+// divisor -- and hipcc's expansion of each (above) shares nothing, because v_div_scale looks at both operands.  With the
+// correctly rounded reciprocal r = RN(1/t) of rcp_ieee's Newton core, ONE residual step per component is enough
+// (Markstein): q0 = RN(a r); rho = a - q0 t (exact in an FMA); q = RN(q0 + rho r) = RN(a / t).  That is a statement about
+// significands only -- every step is an IEEE operation, so it scales with the operands' exponents as long as nothing
+// leaves the normal range -- and tests/test_div3_gpu.py checks it on the GPU for EVERY pair of significands (2^46
+// pairs, tools/div3_exhaustive.py; a sample of divisors in the suite) against the compiler's division.  Exponents:
+// t in [2^-40, 2^40] and each component 0 or in [2^-60, 2^60] keep q0, rho and q normal and rho exact; anything else (and a
+// NaN or infinite component, which the magnitude test rejects or v_div_fixup resolves exactly as in hipcc's sequence) takes
+// the compiler's division, wave-uniformly.  v_div_fixup also gives a zero numerator its sign (q0 + rho r would turn -0
+// into +0).  16 VALU + 9 of guards instead of 36: Cornell 1080p 2.13 -> 2.01 ms (without the guards 1.96); the showcase
+// kernel, bound by latency rather than by VALU issue, pays 1 % for the guards' branches (4.10 -> 4.14).
+PT_DEV float div3_core(float a, float t, float r) {
+    const float q0 = a * r;
+    return __builtin_amdgcn_div_fixupf(fma_(fma_(-t, q0, a), r, q0), t, a);
+}
+PT_DEV bool div3_in_range(f3 a, float t) {
+    // components: zero (either sign) or |a| >= 2^-60 -- as integers, (bits << 1) - 2 sends +-0 to the top and orders the rest
+    const uint32_t lo = min(min(__float_as_uint(a.x) * 2u - 2u, __float_as_uint(a.y) * 2u - 2u), __float_as_uint(a.z) * 2u - 2u);
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    const float at = __builtin_fabsf(t);
+    return lo >= (0x21800000u * 2u - 2u) && hi <= 0x1p60f && at >= 0x1p-40f && at <= 0x1p40f;
+}
+// (out of line: inlined, the three divisions of the fallback were ~40 instructions at each of ~30 call sites -- 8 KB more
+// code per kernel and most of the gain gone)
+__device__ __attribute__((noinline)) f3 div3_slow(f3 a, float t) { return f3{a.x / t, a.y / t, a.z / t}; }
+PT_DEV f3 div3(f3 a, float t) {
+    const float r0 = __builtin_amdgcn_rcpf(t);
+    const float r = fma_(fma_(-t, r0, 1.0f), r0, r0);
+    f3 q = f3{div3_core(a.x, t, r), div3_core(a.y, t, r), div3_core(a.z, t, r)};
+    const bool ok = div3_in_range(a, t);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+        const f3 s = div3_slow(a, t);
+        q.x = ok ? q.x : s.x;
+        q.y = ok ? q.y : s.y;
+        q.z = ok ? q.z : s.z;
+    }
+    return q;
+}
+PT_DEV f3 operator/(f3 a, float t) { return div3(a, t); }
 PT_DEV float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 PT_DEV f3 cross(f3 a, f3 b) {
     return f3{fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))};

@@ -832,6 +832,48 @@ __global__ void rcp_check_kernel(unsigned int *out) {
     }
 }
 
+// exhaustive check of div3's core: for the divisors with significand index [first, first + count) (t = 1.m) EVERY
+// numerator significand (a = 1.m', 2^23 of them), against the compiler's IEEE division; plus, per divisor, the same numerators
+// through div3 itself with exponents chosen by `mode` (0: a in [1, 2); 1: a = m' * 2^-149 .. subnormal and tiny, t scaled by
+// 2^-30; 2: a scaled by 2^70, t by 2^-35: the fallback's ranges).  out[0] = mismatches, out[1..8] = first offending
+// {a bits, t bits} pairs (4 of them).
+__global__ void div3_check_kernel(uint32_t first, uint32_t count, int mode, unsigned int *out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count)
+        return;
+    float t = __uint_as_float(0x3f800000u | ((first + j) & 0x7fffffu));
+    if (mode == 1)
+        t *= 0x1p-30f;
+    if (mode == 2)
+        t *= 0x1p-35f;
+    const float r0 = __builtin_amdgcn_rcpf(t);
+    const float r = fma_(fma_(-t, r0, 1.0f), r0, r0);
+    unsigned int bad = 0;
+    for (uint32_t m = 0; m < (1u << 23); m += 3) {
+        f3 a;
+        if (mode == 0)
+            a = mk3(__uint_as_float(0x3f800000u | m), __uint_as_float(0x3f800000u | ((m + 1) & 0x7fffffu)),
+                    __uint_as_float(0x3f800000u | ((m + 2) & 0x7fffffu)));
+        else if (mode == 1)
+            a = mk3(__uint_as_float(m), -__uint_as_float(0x00800000u + m * 16u), __uint_as_float(0x0c000000u + m));
+        else
+            a = mk3(__uint_as_float(0x3f800000u | m) * 0x1p70f, __uint_as_float(0x7f000000u + 2u * m), -__uint_as_float(0x3f800000u | m));
+        const f3 want = f3{a.x / t, a.y / t, a.z / t};
+        const f3 got = mode == 0 ? f3{div3_core(a.x, t, r), div3_core(a.y, t, r), div3_core(a.z, t, r)} : div3(a, t);
+        const bool ne = (__float_as_uint(want.x) != __float_as_uint(got.x) && !(want.x != want.x && got.x != got.x)) ||
+                        (__float_as_uint(want.y) != __float_as_uint(got.y) && !(want.y != want.y && got.y != got.y)) ||
+                        (__float_as_uint(want.z) != __float_as_uint(got.z) && !(want.z != want.z && got.z != got.z));
+        if (ne && bad < 4) {
+            const unsigned int k = atomicAdd(&out[0], 1u);
+            if (k < 4) {
+                out[1 + 2 * k] = __float_as_uint(a.x);
+                out[2 + 2 * k] = __float_as_uint(t);
+            }
+            ++bad;
+        }
+    }
+}
+
 // deterministic-math probe for tests: op 0 sin, 1 cos, 2 exp, 3 log, 4 pow
 __global__ void detmath_kernel(int op, const float *x, const float *y, int n, float *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -10,5 +10,5 @@ for c in $CFGS; do
   echo "pmc $c done"
 done
 cd $R
-( for c in "showcase1080:showcase 1920 1080 4" "fluid:fluid 1920 1080 2" "many:many 1920 1080 4"; do echo "### ${c%%:*}"; PTRT_AMD_LIB=$V/libptrt_stats.so python tools/trav_stats.py ${c#*:}; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r2w/lane_occupancy.txt
+( for c in "cornell1080:cornell 1920 1080 4" "showcase1080:showcase 1920 1080 4" "fluid:fluid 1920 1080 2" "many:many 1920 1080 4"; do echo "### ${c%%:*}"; PTRT_AMD_LIB=$V/libptrt_stats.so python tools/trav_stats.py ${c#*:}; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r2w/lane_occupancy.txt
 tail -5 gpurun_out/r2w/lane_occupancy.txt

@@ -1339,6 +1339,18 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     f3 avg_color = mk3(0.0f);
     auto close_sample = [&](f3 a) { avg_color = avg_color + a; }; // scene_kernels.cuh:171-176
     uint32_t n_ext = 0, n_shadow = 0; // wave totals (uniform)
+    // PMODE 1 at five waves per SIMD has no scalar registers to spare either: two loop-carried counters ended up in a VGPR
+    // lane that itself lived in scratch -- a load, a v_writelane and a store per iteration, 0.5 GB of writes per 1080p
+    // frame.  Its totals sit in LDS instead, one 64-bit add per iteration: {extension rays, shadow rays << 32} in the 32
+    // spare bytes behind the last mesh's packets (PAIR_PAD leaves them).
+    constexpr bool LDS_COUNT = (PMODE == 1) && (WG == 1);
+    unsigned long long *lds_count =
+        LDS_COUNT ? (unsigned long long *)(PL.tris + K.pair_tri_slots * 3 + (K.pair_meshes - 1) * PAIR_PAD) : nullptr;
+    if (LDS_COUNT) {
+        if (lane == 0)
+            *lds_count = 0ull;
+        wave_sync();
+    }
 
     int s = inside ? 0 : K.spp;
     int bounce = 0;
@@ -1451,7 +1463,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         hit.front_face = true;
         f3 L = mk3(0.0f), light_scale = mk3(0.0f), shadow_o = mk3(0.0f);
         float pdf_sample = 1.0f, shadow_tmax = 0.0f, light_att = 1.0f;
-        n_ext += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
+        if (!LDS_COUNT)
+            n_ext += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
         if (live) {
             if (h.mesh < 0) {
                 if (bounce == 0 && s == 0) { // G-buffer of the first sample's first hit (scene_kernels.cuh:181-193)
@@ -1564,7 +1577,15 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 }
             }
         }
-        n_shadow += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow));
+        if (LDS_COUNT) {
+            const unsigned long long add = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)) |
+                                           ((unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow)) << 32);
+            if (lane == 0)
+                __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long *)lds_count, add, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            n_shadow += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow));
+        }
 
         if (PMODE == 1)
             TS_ADD(9, t_pc);
@@ -1716,6 +1737,12 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         }
     }
     if (K.counters) {
+        if (LDS_COUNT) {
+            wave_sync();
+            const unsigned long long t = *lds_count;
+            n_ext = (uint32_t)t;
+            n_shadow = (uint32_t)(t >> 32);
+        }
         const uint32_t a = n_ext, b = n_shadow,
                        c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside)) * (uint32_t)K.spp;
         // one slot of three counters per workgroup, plain read-modify-write (only this workgroup touches

@@ -396,8 +396,9 @@ def main():
         n3 = max(2, min(args.steps, 6))
         f3 = Farm(P, torch, dist, tilefarm, env, c["scene"], c["width"], c["height"], c["spp"], c["depth"])
         m3 = f3.measure(n3, 1)
+        part3 = "interleaved 8-row strip set(s)" if f3.strips else "band(s)"
         f3.close()
-        c3 = {"workload": f"showcase {c['width']}x{c['height']} {c['spp']}spp {c['depth']}-bounce, {world} band(s)",
+        c3 = {"workload": f"showcase {c['width']}x{c['height']} {c['spp']}spp {c['depth']}-bounce, {world} {part3}",
               "metric": "Mrays/s", "value": round(m3["rays"] / m3["dt"] / 1e6, 2), "n_gpus": world, "steps": n3, "warmup": 1,
               "ms_per_step": round(m3["dt"] / n3 * 1e3, 4), "fps": round(n3 / m3["dt"], 3), "scaling": "strong",
               "rays_per_frame": round(m3["rays"] / n3), "kernel_ms_max_over_ranks": round(m3["kernel_ms"], 4)}

@@ -366,12 +366,14 @@ PT_DEV bool blas_any(const KParams &K, int root_ref, bool alive, const RayO &r, 
 struct MeshHead {
     f3 bmin, bmax;
     int root_ref, flags; // flags bit0 has_transform, bit1 skipped by shadow rays (transmission > 0.5)
+    int mesh;            // mesh id
 };
 PT_DEV MeshHead load_mesh_head(const KParams &K, int m) {
     const float4 a = K.mesh_recs[m * MESH_REC_F4 + 0], b = K.mesh_recs[m * MESH_REC_F4 + 1];
     MeshHead h;
     h.bmin = mk3(a.x, a.y, a.z);
     h.root_ref = __float_as_int(a.w);
+    h.mesh = m;
     h.bmax = mk3(b.x, b.y, b.z);
     h.flags = __float_as_int(b.w);
     return h;

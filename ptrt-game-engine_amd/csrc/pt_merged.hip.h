@@ -39,8 +39,7 @@ PT_DEV int build_pairs_merged(const KParams &K, const PairLds &L, int lane, bool
             bool hb;
             if (mh.flags & 1) {
                 float ds;
-                const int m = __builtin_amdgcn_readfirstlane(L.meshtab[i].w);
-                const RayO lr = local_ray(K, m, we, ds);
+                const RayO lr = local_ray(K, mh.mesh, we, ds);
                 hb = ext && slab(mh.bmin, mh.bmax, lr, T_FAR, tE);
             } else {
                 hb = ext && slab(mh.bmin, mh.bmax, we, T_FAR, tE);
@@ -63,8 +62,7 @@ PT_DEV int build_pairs_merged(const KParams &K, const PairLds &L, int lane, bool
         bool hb;
         if (mh.flags & 1) {
             float ds;
-            const int m = __builtin_amdgcn_readfirstlane(L.meshtab[i].w);
-            const RayO lr = local_ray(K, m, ws, ds);
+            const RayO lr = local_ray(K, mh.mesh, ws, ds);
             hb = sh && slab(mh.bmin, mh.bmax, lr, stmax * ds, tE);
         } else {
             hb = sh && slab(mh.bmin, mh.bmax, ws, stmax, tE);
@@ -141,7 +139,7 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 r = src;
                 oi = (int)(e >> 7);
                 isany = any;
-                const int4 mt = L.meshtab[oi];
+                const int4 mt = staged_mesh_entry(L, oi);
                 pair_ray_from(K, mt, po, pd, dirScale);
                 pr = make_ray(po, pd);
                 xf = (mt.z & 1) != 0;
@@ -340,7 +338,7 @@ PT_DEV void trace_merged(const KParams &K, const PairLds &L, int lane, bool ext,
         h.slot = -1;
         return;
     }
-    const int4 mt = L.meshtab[(int)((key >> 24) & 0xffu)];
+    const int4 mt = staged_mesh_entry(L, (int)((key >> 24) & 0xffu));
     h.t = __uint_as_float((uint32_t)(key >> 32));
     h.mesh = mt.w;
     h.slot = (int)(key & 0xffffffu);

@@ -62,7 +62,7 @@ struct PairLds {
 };
 constexpr int LDS_LIGHTS = 8;
 constexpr int LDS_EXTRA_FIXED = 16 * 8 + 64 * 8; // jitter table + blue-noise values
-constexpr int LEAF_PAIR_BYTES = 512 + 1152;
+constexpr int LEAF_PAIR_BYTES = 512 + 1088; // lkey + owner (64 lanes x 17 tests)
 // PMODE 3: TLAS leaves a ray may have in one fill of the pair list (a power of two <= 4) and the pairs that end a fill
 #ifndef PT_TLAS_SLOTS
 #define PT_TLAS_SLOTS 1
@@ -76,18 +76,23 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     char *p = (char *)base;
     l.tris = (float4 *)p;
     p += tri_slots ? ((size_t)tri_slots * 48 + (size_t)meshes * PAIR_PAD * 16) : 0;
-    l.meshtab = (int4 *)p;
-    p += (size_t)meshes * 16;
+    l.meshtab = (int4 *)p; // (PMODE 1 only: {first slot, count, flags, mesh id}; the other modes read the staged heads)
+    p += tri_slots ? (size_t)meshes * 16 : 0;
     l.meshbox = (float4 *)p;
     p += (size_t)meshes * 32;
     l.best = (unsigned long long *)p;
+    // the any-hit traversals use the first half of `best` as a plane of ray limits; their blocked flags take the second
+    // (PMODE 4 walks both kinds of ray at once and keeps its flags apart)
+    l.occ = (uint32_t *)(p + 256);
     p += tlas_leaf ? 512 * TLAS_SLOTS : 512; // (PMODE 3: one minimum per ray and leaf slot)
     l.pairs = (uint32_t *)p;
     // 16-bit entries {lane, mesh order << 6}; PMODE 3 holds one TLAS leaf per ray at a time
     // (PMODE 4 keeps the pairs of both ray kinds in one list of pair_cap 16-bit entries)
     p += pair_cap ? (size_t)pair_cap * 2 : tlas_leaf ? ((size_t)tlas_leaf * 64 + TLAS_FILL_TARGET) * 2 : (size_t)meshes * 128;
-    l.occ = (uint32_t *)p;
-    p += 256;
+    if (pair_cap) {
+        l.occ = (uint32_t *)p;
+        p += 256;
+    }
     l.stack = (uint2 *)p;
     p += (size_t)stack_entries * 512;
     l.tstack = (uint2 *)p;
@@ -102,15 +107,14 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
 
 // PMODE 2 in 256-thread workgroups (path_trace_kernel<.., WG = 4>): mesh table, mesh heads and the top levels of every
 // BLAS are ONE copy per workgroup at the base of its LDS; behind them each wave has its own lists and stacks.
-PT_DEV size_t shared_lds_bytes(int meshes) { return (size_t)meshes * (48 + TOP_NODES * 64); }
+PT_DEV size_t shared_lds_bytes(int meshes) { return (size_t)meshes * (32 + TOP_NODES * 64); }
 PT_DEV size_t wave_lds_bytes(int meshes, int stack_entries) {
     return 512 + (size_t)meshes * 128 + 256 + (size_t)stack_entries * 512 + LEAF_PAIR_BYTES;
 }
 PT_DEV PairLds carve_pair_lds_wg(void *base, int wave, int meshes, int stack_entries) {
     PairLds l{};
     char *p = (char *)base;
-    l.meshtab = (int4 *)p;
-    p += (size_t)meshes * 16;
+    l.meshtab = nullptr;
     l.meshbox = (float4 *)p;
     p += (size_t)meshes * 32;
     l.topnodes = (const float4 *)p;
@@ -214,8 +218,16 @@ PT_DEV MeshHead staged_mesh_head(const PairLds &L, int i) {
     h.bmin = mk3(a.x, a.y, a.z);
     h.bmax = mk3(b.x, b.y, b.z);
     h.root_ref = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));
-    h.flags = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
+    const int fm = __builtin_amdgcn_readfirstlane(__float_as_int(b.w)); // (staged as flags | mesh id << 8)
+    h.flags = fm & 0xff;
+    h.mesh = fm >> 8;
     return h;
+}
+// the same mesh as a pair sees it, per lane: {root reference, 0, flags, mesh id} (PMODE 2, 4; PMODE 1 has L.meshtab)
+PT_DEV int4 staged_mesh_entry(const PairLds &L, int i) {
+    const int root = __float_as_int(lds_ld1((const float *)L.meshbox, 8 * i + 3));
+    const int fm = __float_as_int(lds_ld1((const float *)L.meshbox, 8 * i + 7));
+    return make_int4(root, 0, fm & 0xff, fm >> 8);
 }
 
 // Exclusive prefix sum and total of the lanes' leaf sizes (< 32) by bit planes: five ballots and mbcnt pairs, no LDS --
@@ -252,8 +264,7 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
         bool hb;
         if (mh.flags & 1) {
             float ds;
-            const int m = __builtin_amdgcn_readfirstlane(L.meshtab[i].w);
-            const RayO lr = local_ray(K, m, w, ds);
+            const RayO lr = local_ray(K, mh.mesh, w, ds);
             hb = alive && slab(mh.bmin, mh.bmax, lr, ANY ? tMax * ds : T_FAR, tE);
         } else {
             hb = alive && slab(mh.bmin, mh.bmax, w, ANY ? tMax : T_FAR, tE);
@@ -426,11 +437,11 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
 // lanes take the next pairs -- rank by ballot/mbcnt, `next` is wave-uniform, no atomics -- commit
 // their finished pair with the same 64-bit min and start over, while the other lanes keep their
 // traversal state.  Every pair is still traversed exactly as before, so the bits cannot change.
-// mesh of a pair entry.  GEN = false: `order` indexes the single TLAS leaf (L.meshtab).  GEN = true (general TLAS,
+// mesh of a pair entry.  GEN = false: `order` indexes the single TLAS leaf (the staged heads).  GEN = true (general TLAS,
 // PMODE 3): `order` indexes the TLAS leaf the RAY is currently at (L.leafx[r]), the head comes from the mesh records.
 template <bool GEN> PT_DEV int4 pair_mesh(const KParams &K, const PairLds &L, int r, int order) {
     if (!GEN)
-        return L.meshtab[order];
+        return staged_mesh_entry(L, order);
     // (root reference and flags from the leaf-order copy of the heads; the mesh id only matters for an instance's matrices)
     // (order = leaf slot of this fill | index in that leaf << 2)
     const int j = L.leafx[(order & (TLAS_SLOTS - 1)) * 64 + r] + (order >> 2);
@@ -671,7 +682,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
         h.slot = -1;
         return h;
     }
-    const int4 mt = L.meshtab[(int)((key >> 24) & 0xffu)];
+    const int4 mt = staged_mesh_entry(L, (int)((key >> 24) & 0xffu));
     h.t = __uint_as_float((uint32_t)(key >> 32));
     h.mesh = mt.w;
     h.slot = (int)(key & 0xffffffu);
@@ -1222,8 +1233,9 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             const int m = K.tlas_mesh_ids[lf.x + i];
             const MeshHead mh = load_mesh_head(K, m);
             PL.meshbox[2 * i] = K.mesh_recs[m * MESH_REC_F4 + 0];
-            PL.meshbox[2 * i + 1] = K.mesh_recs[m * MESH_REC_F4 + 1];
-            PL.meshtab[i] = make_int4(mh.root_ref, 0, mh.flags, m);
+            float4 hb = K.mesh_recs[m * MESH_REC_F4 + 1];
+            hb.w = __int_as_float((mh.flags & 0xff) | (m << 8));
+            PL.meshbox[2 * i + 1] = hb;
         }
         // the first TOP_NODES nodes of each tree (its top TOP_LEVELS levels: the host numbers them in level order)
         float4 *top = const_cast<float4 *>(PL.topnodes);
@@ -1257,12 +1269,12 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             const int m = K.tlas_mesh_ids[lf.x + i];
             const MeshHead mh = load_mesh_head(K, m);
             PL.meshbox[2 * i] = K.mesh_recs[m * MESH_REC_F4 + 0];
-            PL.meshbox[2 * i + 1] = K.mesh_recs[m * MESH_REC_F4 + 1];
+            float4 hb = K.mesh_recs[m * MESH_REC_F4 + 1];
+            hb.w = __int_as_float((mh.flags & 0xff) | (m << 8)); // (flags and mesh id in one word: staged_mesh_head)
+            PL.meshbox[2 * i + 1] = hb;
             if (PMODE == 1) {
                 const int2 leaf = K.leaves[~mh.root_ref];
                 PL.meshtab[i] = make_int4(leaf.x, leaf.y, mh.flags, m);
-            } else {
-                PL.meshtab[i] = make_int4(mh.root_ref, 0, mh.flags, m);
             }
         }
         __syncthreads();

@@ -579,7 +579,7 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
 // shadow pairs get what is left of a 10-KB LDS budget (16 waves per CU), at least 64 (one mesh per pass), at most
 // another 64 * meshes (everything in one pass)
 int merged_pair_cap(const ptrt_ctx *c) {
-    const size_t rest = (size_t)c->pair_meshes * 48 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
+    const size_t rest = (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
     const int lo = 64 * c->pair_meshes + 64, hi = 128 * c->pair_meshes;
     int cap = rest < 10240 ? (int)((10240 - rest) / 2) / 64 * 64 : 0;
     cap = cap < lo ? lo : cap;
@@ -587,14 +587,14 @@ int merged_pair_cap(const ptrt_ctx *c) {
 }
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
     if (pmode == 4)
-        return (size_t)c->pair_meshes * 48 + 512 + 256 + (size_t)merged_pair_cap(c) * 2 +
+        return (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)merged_pair_cap(c) * 2 +
                (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
     if (pmode == 3) // no mesh table; pair list for one TLAS leaf per ray; TLAS stack + the rays' leaf starts
-        return ((size_t)c->tlas_max_leaf * 64 + pt::TLAS_FILL_TARGET) * 2 + 512 * pt::TLAS_SLOTS + 256 +
+        return ((size_t)c->tlas_max_leaf * 64 + pt::TLAS_FILL_TARGET) * 2 + 512 * pt::TLAS_SLOTS +
                (size_t)c->stack_entries * 64 * sizeof(uint2) + (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 +
                256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES;
-    const size_t common = (size_t)c->pair_meshes * 48 + (size_t)c->pair_meshes * 128 + // (mesh table + staged heads, 16-bit pair entries)
-                          512 + 256;
+    // staged heads (PMODE 1: and the mesh table), 16-bit pair entries, the rays' minima (whose second half holds the any-hit flags)
+    const size_t common = (size_t)c->pair_meshes * (pmode == 1 ? 48 : 32) + (size_t)c->pair_meshes * 128 + 512;
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
 }
@@ -1925,19 +1925,20 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // PMODE 1 stages its shading inputs behind the lists (KParams::lds_extra) while that keeps the workgroup within the
     // LDS that the occupancy its kernel is built for leaves each wave (pt::lds_per_wave)
     size_t lds_main = lds + (size_t)c->lds_pad;
-    if (pmode == 1 && c->stage) {
+    if (pmode == 1 && c->stage) { // (piece by piece, while they fit)
+        const size_t at = (lds + 15) & ~(size_t)15, budget = (size_t)pt::lds_per_wave(1, full);
         size_t extra = pt::LDS_EXTRA_FIXED;
-        int flags = 4;
-        if ((c->stage & 1) && c->n_lights > 0 && c->n_lights <= pt::LDS_LIGHTS) {
-            flags |= 1;
-            extra += (size_t)c->n_lights * 64;
-        }
-        if ((c->stage & 2) && c->pair_meshes <= 42) { // (96 B per mesh: up to 4 KB)
-            flags |= 2;
-            extra += (size_t)c->pair_meshes * 96;
-        }
-        const size_t at = (lds + 15) & ~(size_t)15;
-        if (at + extra + (size_t)c->lds_pad <= (size_t)pt::lds_per_wave(1, full)) {
+        if (at + extra + (size_t)c->lds_pad <= budget) {
+            int flags = 4;
+            const size_t lights = (size_t)c->n_lights * 64, mats = (size_t)c->pair_meshes * 96;
+            if ((c->stage & 1) && c->n_lights > 0 && c->n_lights <= pt::LDS_LIGHTS && at + extra + lights + (size_t)c->lds_pad <= budget) {
+                flags |= 1;
+                extra += lights;
+            }
+            if ((c->stage & 2) && c->pair_meshes <= 42 && at + extra + mats + (size_t)c->lds_pad <= budget) {
+                flags |= 2;
+                extra += mats;
+            }
             K.lds_extra = (int)at;
             K.lds_flags = flags;
             lds_main = at + extra + (size_t)c->lds_pad;
@@ -1964,7 +1965,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     else if (pmode == 2 && c->lds_nodes && c->stack_entries > 0) {
         // four tiles per workgroup, one LDS copy of the mesh heads and of the BLAS top levels (north star: "BVH nodes
         // ... staged in LDS")
-        const size_t lds4 = (size_t)c->pair_meshes * (48 + pt::TOP_NODES * 64) +
+        const size_t lds4 = (size_t)c->pair_meshes * (32 + pt::TOP_NODES * 64) +
                             4 * (512 + (size_t)c->pair_meshes * 128 + 256 + (size_t)c->stack_entries * 512 + pt::LEAF_PAIR_BYTES);
         if (lds4 > 64 * 1024)
             return fail(c, PTRT_E_INVALID, "lds_nodes: %zu bytes of LDS per workgroup", lds4);

@@ -80,3 +80,13 @@ def test_eight_bands_of_a_small_showcase_frame_equal_the_oracle(P, O, blue_noise
         gpu, cpu = render_both(P, O, b, blue_noise, SPP, DEPTH, frames=2)
         assert_frames_equal(gpu, cpu)
         b.close()
+
+
+def test_showcase_4k_8spp_frame_equals_the_oracle(P, O, blue_noise):
+    """configs[3]'s frame at its full size against the oracle (16 host threads, ~10 s): every buffer, generator state, ray count."""
+    from common import assert_frames_equal, render_both
+    s = P.Scene(W4K, H4K)
+    P.scenes.showcase(s)
+    gpu, cpu = render_both(P, O, s, blue_noise, SPP, DEPTH, 1, threads=16)
+    assert_frames_equal(gpu, cpu)
+    s.close()

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from common import assert_frames_equal, render_both
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -183,3 +185,14 @@ def test_full_size_traversal_variants_agree(P, scene):
                 assert np.array_equal(av, bv), f"{scene} {opts} frame {f}: {k} differs in {(av != bv).sum()} words"
             assert a["stats"] == b["stats"]
     assert ref[0]["accum"].any()
+
+
+@pytest.mark.parametrize("scene,spp,frames", [("cornell", 4, 2), ("showcase", 4, 1)])
+def test_full_size_frames_equal_the_oracle(P, O, blue_noise, scene, spp, frames):
+    """BASELINE configs[1] and configs[2] at their FULL size (1920x1080, 4 spp, 4 bounces): every buffer, generator state and ray
+    count of the GPU frame against the oracle's (16 host threads: about a second per Cornell frame, a few for the showcase)."""
+    s = P.Scene(1920, 1080)
+    getattr(P.scenes, scene)(s)
+    gpu, cpu = render_both(P, O, s, blue_noise, spp, 4, frames, threads=16)
+    assert_frames_equal(gpu, cpu)
+    s.close()

@@ -129,3 +129,27 @@ def test_refit_and_rebuild_behind_a_real_tlas(P, O, blue_noise, rebuild):
         assert_frames_equal([g], [c])
     assert (g["object_id"] == blob).sum() > 20
     s.close()
+
+
+@pytest.mark.gpu
+def test_fluid_full_size_refit_frame_equals_the_oracle(P, O, blue_noise):
+    """BASELINE configs[4] at its full size (131,072-triangle water surface, 1920x1080, 2 spp): the built frame, then the
+    frame after a vertex update + GPU refit, against the oracle on the host-refitted tree -- every buffer and generator state."""
+    W, H = 1920, 1080
+    s = P.Scene(W, H)
+    w, _ = P.scenes.fluid(s, cells=256, t=0.0)
+    gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 1, threads=16)
+    assert_frames_equal(gpu, cpu)
+    s.setVertices(w, P.scenes.water_vertices(256, 0.7))
+    s.refitObjectChanges()
+    s.reset_rng(P.DEFAULT_SEED)
+    rng = O.xorwow_init(P.DEFAULT_SEED, 0, W * H)
+    rgb = s.render_to_host()
+    c = O.render(s.flatten(), W, H, 2, 4, 0, blue_noise, rng, threads=16)
+    assert np.array_equal(s.read(P.BUF_OBJECT_ID), c["object_id"])
+    for k, b in (("accum", P.BUF_ACCUM), ("depth", P.BUF_DEPTH), ("normal", P.BUF_NORMAL)):
+        assert np.array_equal(s.read(b).view(np.uint32), c[k].view(np.uint32)), k
+    assert np.array_equal(s.read(P.BUF_RNG), rng)
+    assert np.array_equal(rgb, O.tonemap(c["accum"], W, H, threads=16))
+    assert not np.array_equal(s.read(P.BUF_DEPTH), gpu[0]["depth"])  # the surface did move
+    s.close()

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void prep_kernel(float4 *__restrict__ g4, floa
                 seed ^= seed >> 14;
                 const float r1 = ((float)(seed & 0xFFFFu) + 0.5f) / 65536.0f;
                 const float r2 = ((float)((seed * 0x343fdu + 0xc0f5u) & 0xFFFFu) + 0.5f) / 65536.0f;
-                const float r = __builtin_sqrtf(r1);
+                const float r = sqrt_ieee(r1);
                 const float phi = 6.2831853f * r2;
                 const f3 disk = mk3(r * det_cos(phi), r * det_sin(phi), 0.0f) * lens_radius;
                 const f3 offset = cam_u * disk.x + cam_v * disk.y;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(float4 *__restrict__ oh1,
     nmean = nmean * inv_n;
     nm2 = nm2 * inv_n;
     const f3 nvar = max3(nm2 - nmean * nmean, mk3(0.0f));
-    const f3 nstd = mk3(__builtin_sqrtf(nvar.x), __builtin_sqrtf(nvar.y), __builtin_sqrtf(nvar.z));
+    const f3 nstd = mk3(sqrt_ieee(nvar.x), sqrt_ieee(nvar.y), sqrt_ieee(nvar.z));
     const f3 soft_min = nmean - nstd * S.clamp_scale;
     const f3 soft_max = nmean + nstd * S.clamp_scale;
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(float4 *__restrict__ oh1,
     float alpha = 1.0f, nlen = 1.0f;
     if (valid) {
         const f3 var = max3(hist_m2 - (hist_mean * hist_mean), mk3(0.0f));
-        const float std_approx = (__builtin_sqrtf(var.x) + __builtin_sqrtf(var.y) + __builtin_sqrtf(var.z)) * (1.0f / 3.0f);
+        const float std_approx = (sqrt_ieee(var.x) + sqrt_ieee(var.y) + sqrt_ieee(var.z)) * (1.0f / 3.0f);
         const float variance_alpha = std_approx / (std_approx + S.tau);
         const float history_alpha = 1.0f / (hist_len + 1.0f);
         alpha = clampf(max_(variance_alpha, history_alpha), S.min_alpha, 1.0f);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
     f3 res = cc;
     float res_var = cvar;
     if (!is_sky(cd, cn, sky)) {
-        const float var_scale = __builtin_sqrtf(max_(cvar, 1e-6f));
+        const float var_scale = sqrt_ieee(max_(cvar, 1e-6f));
         const float asl = sigma_lum * (1.0f + var_scale * 2.0f);
         const float inv_sl2 = 1.0f / (2.0f * asl * asl + 1e-6f);
         f3 sum = mk3(0.0f);

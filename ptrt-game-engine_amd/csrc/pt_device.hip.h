@@ -105,11 +105,37 @@ PT_DEV f3 div3(f3 a, float t) {
     return q;
 }
 PT_DEV f3 operator/(f3 a, float t) { return div3(a, t); }
+// Correctly rounded sqrt(x), cheaper: hipcc's expansion is v_sqrt_f32, two FMA tests of the neighbouring floats, a pre- and
+// post-scaling for tiny arguments and a class test (16 VALU + the transcendental).  For a mid-range x the reciprocal square
+// root's first-order correction already rounds correctly: r = v_rsq_f32(x); g = x r; h = r / 2; s = g + (x - g g) h, the
+// residual exact in an FMA.  tests/test_misc_gpu.py compares sqrt_ieee with the compiler's sqrtf for EVERY fp32 bit pattern
+// (PT_SQRT_VARIANT 2 adds a coupled Newton step to g and h first); zero, subnormal, huge, negative, infinite and NaN
+// arguments take the compiler's sequence, wave-uniformly.
+#ifndef PT_SQRT_VARIANT
+#define PT_SQRT_VARIANT 1
+#endif
+PT_DEV float sqrt_core(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r, h = 0.5f * r;
+#if PT_SQRT_VARIANT == 2
+    const float e = fma_(-h, g, 0.5f);
+    g = fma_(g, e, g);
+    h = fma_(h, e, h);
+#endif
+    return fma_(fma_(-g, g, x), h, g);
+}
+PT_DEV float sqrt_ieee(float x) {
+    float s = sqrt_core(x);
+    const bool mid = (__float_as_uint(x) - 0x21800000u) < (0x5d800000u - 0x21800000u); // positive, 2^-60 <= x < 2^60
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!mid) != 0ull, 0))
+        s = mid ? s : __builtin_sqrtf(x);
+    return s;
+}
 PT_DEV float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 PT_DEV f3 cross(f3 a, f3 b) {
     return f3{fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))};
 }
-PT_DEV float length(f3 v) { return __builtin_sqrtf(dot(v, v)); }
+PT_DEV float length(f3 v) { return sqrt_ieee(dot(v, v)); }
 PT_DEV f3 normalize(f3 v) {
     const float len = length(v);
     return (len > 0) ? (v / len) : mk3(0.0f);
@@ -284,11 +310,11 @@ PT_DEV float det_acos(float x) {
     const float PI_F = 0x1.921fb6p+1f, PIO2_F = 0x1.921fb6p+0f;
     if (x > 0.5f) {
         const float z = 0.5f * (1.0f - x);
-        return 2.0f * det_asin_core(__builtin_sqrtf(z), z);
+        return 2.0f * det_asin_core(sqrt_ieee(z), z);
     }
     if (x < -0.5f) {
         const float z = 0.5f * (1.0f + x);
-        return PI_F - 2.0f * det_asin_core(__builtin_sqrtf(z), z);
+        return PI_F - 2.0f * det_asin_core(sqrt_ieee(z), z);
     }
     return PIO2_F - det_asin_core(x, x * x);
 }
@@ -427,18 +453,18 @@ PT_DEV float geometrySmithTransmission(f3 N, f3 V, f3 L, float roughness) {
 }
 PT_DEV f3 calculateIridescence(float thickness, float cosTheta, float filmIOR, float baseIOR) {
     cosTheta = clamp01(cosTheta);
-    const float sinTheta = __builtin_sqrtf(1.0f - cosTheta * cosTheta);
+    const float sinTheta = sqrt_ieee(1.0f - cosTheta * cosTheta);
     const float sinThetaFilm = sinTheta / filmIOR;
     if (sinThetaFilm * sinThetaFilm > 1.0f)
         return mk3(1.0f);
-    const float cosThetaFilm = __builtin_sqrtf(1.0f - sinThetaFilm * sinThetaFilm);
+    const float cosThetaFilm = sqrt_ieee(1.0f - sinThetaFilm * sinThetaFilm);
     const float OPD = 2.0f * filmIOR * thickness * cosThetaFilm;
     float Ra = (1.0f - filmIOR) / (1.0f + filmIOR);
     Ra *= Ra;
     float Rb = (filmIOR - baseIOR) / (filmIOR + baseIOR);
     Rb *= Rb;
-    const float sqrtR1R2 = __builtin_sqrtf(Ra * Rb);
-    float R_max = (__builtin_sqrtf(Ra) + __builtin_sqrtf(Rb));
+    const float sqrtR1R2 = sqrt_ieee(Ra * Rb);
+    float R_max = (sqrt_ieee(Ra) + sqrt_ieee(Rb));
     R_max *= R_max;
     const float inv_R_max = 1.0f / (R_max + 1e-6f);
     const float d0 = TWO_PI_F * OPD * (1.0f / 650.0f);
@@ -496,7 +522,7 @@ PT_DEV void orthoBasis(f3 N, f3 &T, f3 &B) {
         B = mk3(0.0f, 1.0f, 0.0f);
         return;
     }
-    const f3 Nn = N * (1.0f / __builtin_sqrtf(len2));
+    const f3 Nn = N * (1.0f / sqrt_ieee(len2));
     const float s = __builtin_copysignf(1.0f, Nn.z);
     const float a = -1.0f / (s + Nn.z);
     const float b = Nn.x * Nn.y * a;
@@ -512,7 +538,7 @@ PT_DEV f3 sample_cone_direction(Rng &rng, f3 cone_dir, float cos_theta_max) {
     const float u1 = rng_uniform(rng);
     const float u2 = rng_uniform(rng);
     const float cos_theta = 1.0f - u1 * (1.0f - cos_theta_max);
-    const float sin_theta = __builtin_sqrtf(max_(0.0f, 1.0f - cos_theta * cos_theta));
+    const float sin_theta = sqrt_ieee(max_(0.0f, 1.0f - cos_theta * cos_theta));
     const float phi = TWO_PI_F * u2;
     float sp, cp;
     det_sincos(phi, sp, cp);
@@ -521,11 +547,11 @@ PT_DEV f3 sample_cone_direction(Rng &rng, f3 cone_dir, float cos_theta_max) {
 PT_DEV f3 sample_cosine_hemisphere(Rng &rng) {
     const float u1 = rng_uniform(rng);
     const float u2 = rng_uniform(rng);
-    const float r = __builtin_sqrtf(u1);
+    const float r = sqrt_ieee(u1);
     const float phi = TWO_PI_F * u2;
     float sp, cp;
     det_sincos(phi, sp, cp);
-    return mk3(r * cp, r * sp, __builtin_sqrtf(max_(0.0f, 1.0f - u1)));
+    return mk3(r * cp, r * sp, sqrt_ieee(max_(0.0f, 1.0f - u1)));
 }
 PT_DEV f3 importance_sample_ggx(Rng &rng, f3 N, float roughness) {
     const float a = roughness * roughness;
@@ -534,8 +560,8 @@ PT_DEV f3 importance_sample_ggx(Rng &rng, f3 N, float roughness) {
     float u2 = rng_uniform(rng);
     u2 = min_(u2, 0.9999999f);
     const float phi = TWO_PI_F * u1;
-    const float cosTheta = __builtin_sqrtf((1.0f - u2) / (1.0f + (a2 - 1.0f) * u2));
-    const float sinTheta = __builtin_sqrtf(max_(0.0f, 1.0f - cosTheta * cosTheta));
+    const float cosTheta = sqrt_ieee((1.0f - u2) / (1.0f + (a2 - 1.0f) * u2));
+    const float sinTheta = sqrt_ieee(max_(0.0f, 1.0f - cosTheta * cosTheta));
     float sp, cp;
     det_sincos(phi, sp, cp);
     return to_world(mk3(sinTheta * cp, sinTheta * sp, cosTheta), N);
@@ -748,7 +774,7 @@ PT_DEV bool material_scatter(const Surface &hit, const Material &mat, f3 ray_dir
                     scattered_dir = reflectVec(-V, H);
                     is_specular_bounce = true;
                 } else {
-                    const float cos_t = __builtin_sqrtf(k);
+                    const float cos_t = sqrt_ieee(k);
                     scattered_dir = normalize(eta * (-V) + (eta * VdotH_tir - cos_t) * H);
                 }
             }

@@ -834,6 +834,27 @@ __global__ void rcp_check_kernel(unsigned int *out) {
     }
 }
 
+// exhaustive check of sqrt_ieee: every fp32 bit pattern against the compiler's IEEE sqrtf.  out[0] = mismatches of sqrt_ieee,
+// out[1] = mismatches of the unguarded core over the guarded range, out[2..8] = first offending inputs of sqrt_ieee.
+__global__ void sqrt_check_kernel(unsigned int *out) {
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = tid; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float want = __builtin_sqrtf(x);
+        const float got = sqrt_ieee(x);
+        const uint32_t wu = __float_as_uint(want), gu = __float_as_uint(got);
+        if (wu != gu && !((want != want) && (got != got))) {
+            const unsigned int k = atomicAdd(&out[0], 1u);
+            if (k < 7)
+                out[2 + k] = (uint32_t)b;
+        }
+        const bool mid = ((uint32_t)b - 0x21800000u) < (0x5d800000u - 0x21800000u);
+        if (mid && __float_as_uint(sqrt_core(x)) != wu)
+            atomicAdd(&out[1], 1u);
+    }
+}
+
 // exhaustive check of div3's core: for the divisors with significand index [first, first + count) (t = 1.m) EVERY
 // numerator significand (a = 1.m', 2^23 of them), against the compiler's IEEE division; plus, per divisor, the same numerators
 // through div3 itself with exponents chosen by `mode` (0: a in [1, 2); 1: a = m' * 2^-149 .. subnormal and tiny, t scaled by

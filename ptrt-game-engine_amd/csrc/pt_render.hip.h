@@ -1554,14 +1554,14 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     } else {
                         const f3 toLight = light.position - hit.point;
                         const float light_dist_sq = dot(toLight, toLight);
-                        light_dist = __builtin_sqrtf(light_dist_sq);
+                        light_dist = sqrt_ieee(light_dist_sq);
                         if (light.radius <= 0.0f) {
                             L = toLight / light_dist;
                             pdf_sample = pdf_pick;
                         } else {
                             float sin_theta_max_sq = (light.radius * light.radius) / light_dist_sq;
                             sin_theta_max_sq = min_(sin_theta_max_sq, 0.9999f);
-                            const float cos_theta_max = __builtin_sqrtf(1.0f - sin_theta_max_sq);
+                            const float cos_theta_max = sqrt_ieee(1.0f - sin_theta_max_sq);
                             L = sample_cone_direction(rng, toLight / light_dist, cos_theta_max);
                             const float solid_angle = TWO_PI_F * (1.0f - cos_theta_max);
                             pdf_sample = (solid_angle > 1e-6f) ? (pdf_pick / solid_angle) : pdf_pick;

@@ -2552,6 +2552,22 @@ int ptrt_debug_rcp_check(ptrt_ctx *c, unsigned int *out9) {
     return PTRT_OK;
 }
 
+// test hook: exhaustive sqrt_ieee check; out9[0] = mismatches, out9[1] = mismatches of the bare core in its range, out9[2..8] = inputs
+int ptrt_debug_sqrt_check(ptrt_ctx *c, unsigned int *out9) {
+    if (!ctx_live(c) || !out9)
+        return fail(c, PTRT_E_INVALID, "ptrt_debug_sqrt_check: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    unsigned int *d = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d, 9 * sizeof(unsigned int)));
+    HIP_TRY(c, hipMemset(d, 0, 9 * sizeof(unsigned int)));
+    hipLaunchKernelGGL(pt::sqrt_check_kernel, dim3(4096), dim3(256), 0, c->stream, d);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out9, d, 9 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return PTRT_OK;
+}
+
 // test hook: div3's core for the divisors 1.m, m in [first, first + count), against every numerator significand (mode 0), or
 // div3 with out-of-range exponents (modes 1, 2); out9[0] = mismatches, out9[1..8] = first offending {a, t} bit patterns
 int ptrt_debug_div3_check(ptrt_ctx *c, unsigned int first, unsigned int count, int mode, unsigned int *out9) {

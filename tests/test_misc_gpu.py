@@ -66,6 +66,16 @@ def test_fast_reciprocal_is_ieee_for_every_float(P):
     s.close()
 
 
+def test_fast_square_root_is_ieee_for_every_float(P):
+    """sqrt_ieee (v_rsq_f32 + one exact-residual correction, guarded by exponent) == sqrtf(x) for all 2^32 inputs."""
+    s = P.Scene(16, 16)
+    out = (C.c_uint * 9)()
+    P.lib.ptrt_debug_sqrt_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    assert P.lib.ptrt_debug_sqrt_check(s.ctx, out) == 0
+    assert out[0] == 0 and out[1] == 0, f"{out[0]} mismatches ({out[1]} of the bare core), first inputs: {[hex(v) for v in list(out)[2:9]]}"
+    s.close()
+
+
 def test_render_before_upload_and_bad_scenes(P):
     s = P.Scene(32, 32)
     assert P.lib.ptrt_render(s.ctx, 0, 1, 1, None, 0) == -4          # PTRT_E_NOT_READY

@@ -858,7 +858,8 @@ __global__ void sqrt_check_kernel(unsigned int *out) {
 // exhaustive check of div3's core: for the divisors with significand index [first, first + count) (t = 1.m) EVERY
 // numerator significand (a = 1.m', 2^23 of them), against the compiler's IEEE division; plus, per divisor, the same numerators
 // through div3 itself with exponents chosen by `mode` (0: a in [1, 2); 1: a = m' * 2^-149 .. subnormal and tiny, t scaled by
-// 2^-30; 2: a scaled by 2^70, t by 2^-35: the fallback's ranges).  out[0] = mismatches, out[1..8] = first offending
+// 2^-30; 2: a scaled by 2^70, t by 2^-35: the fallback's ranges; 3: as 0 with the RAW v_rcp_f32 instead of the refined reciprocal -- the negative control).
+// out[0] = mismatches, out[1..8] = first offending
 // {a bits, t bits} pairs (4 of them).
 __global__ void div3_check_kernel(uint32_t first, uint32_t count, int mode, unsigned int *out) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,7 +875,7 @@ __global__ void div3_check_kernel(uint32_t first, uint32_t count, int mode, unsi
     unsigned int bad = 0;
     for (uint32_t m = 0; m < (1u << 23); m += 3) {
         f3 a;
-        if (mode == 0)
+        if (mode == 0 || mode == 3)
             a = mk3(__uint_as_float(0x3f800000u | m), __uint_as_float(0x3f800000u | ((m + 1) & 0x7fffffu)),
                     __uint_as_float(0x3f800000u | ((m + 2) & 0x7fffffu)));
         else if (mode == 1)
@@ -882,7 +883,8 @@ __global__ void div3_check_kernel(uint32_t first, uint32_t count, int mode, unsi
         else
             a = mk3(__uint_as_float(0x3f800000u | m) * 0x1p70f, __uint_as_float(0x7f000000u + 2u * m), -__uint_as_float(0x3f800000u | m));
         const f3 want = f3{a.x / t, a.y / t, a.z / t};
-        const f3 got = mode == 0 ? f3{div3_core(a.x, t, r), div3_core(a.y, t, r), div3_core(a.z, t, r)} : div3(a, t);
+        const f3 got = mode == 0 ? f3{div3_core(a.x, t, r), div3_core(a.y, t, r), div3_core(a.z, t, r)}
+                       : mode == 3 ? f3{div3_core(a.x, t, r0), div3_core(a.y, t, r0), div3_core(a.z, t, r0)} : div3(a, t);
         const bool ne = (__float_as_uint(want.x) != __float_as_uint(got.x) && !(want.x != want.x && got.x != got.x)) ||
                         (__float_as_uint(want.y) != __float_as_uint(got.y) && !(want.y != want.y && got.y != got.y)) ||
                         (__float_as_uint(want.z) != __float_as_uint(got.z) && !(want.z != want.z && got.z != got.z));

@@ -2571,7 +2571,7 @@ int ptrt_debug_sqrt_check(ptrt_ctx *c, unsigned int *out9) {
 // test hook: div3's core for the divisors 1.m, m in [first, first + count), against every numerator significand (mode 0), or
 // div3 with out-of-range exponents (modes 1, 2); out9[0] = mismatches, out9[1..8] = first offending {a, t} bit patterns
 int ptrt_debug_div3_check(ptrt_ctx *c, unsigned int first, unsigned int count, int mode, unsigned int *out9) {
-    if (!ctx_live(c) || !out9 || count == 0 || count > (1u << 23) || mode < 0 || mode > 2)
+    if (!ctx_live(c) || !out9 || count == 0 || count > (1u << 23) || mode < 0 || mode > 3)
         return fail(c, PTRT_E_INVALID, "ptrt_debug_div3_check: bad argument");
     if (int rc = set_device(c))
         return rc;

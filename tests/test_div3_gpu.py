@@ -37,3 +37,14 @@ def test_out_of_range_operands_take_the_ieee_division(P, mode):
     for first in (0, 0x3fffff, (1 << 23) - 512):
         _check(P, s, first, 512, mode)
     s.close()
+
+
+def test_the_checker_rejects_an_unrefined_reciprocal(P):
+    """Negative control: the same residual step on the RAW v_rcp_f32 (1 ulp) instead of the correctly rounded reciprocal is
+    NOT the IEEE quotient for about one divisor significand in fifty (47,045 reported pairs over all 2^46) -- the checker sees it."""
+    s = P.Scene(16, 16)
+    out = (C.c_uint * 9)()
+    P.lib.ptrt_debug_div3_check.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.POINTER(C.c_uint)]
+    assert P.lib.ptrt_debug_div3_check(s.ctx, 0x700000, 16384, 3, out) == 0
+    assert out[0] > 0
+    s.close()

@@ -59,6 +59,7 @@ struct PairLds {
     const float2 *bn;         // 64: the lanes' blue-noise values
     const float4 *lights;     // the scene's light records (4 float4 each) when at most LDS_LIGHTS of them
     const float4 *mats;       // PMODE 1: material records (6 float4) of the leaf's meshes by mesh order
+    unsigned long long *count; // one-wave workgroups: {extension rays, shadow rays << 32} of the wave so far
 };
 constexpr int LDS_LIGHTS = 8;
 constexpr int LDS_EXTRA_FIXED = 16 * 8 + 64 * 8; // jitter table + blue-noise values
@@ -102,6 +103,9 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     l.lkey = (unsigned long long *)p;
     p += 512;
     l.owner = (unsigned char *)p;
+    p += LEAF_PAIR_BYTES - 512;
+    // the wave's ray totals (path_trace_kernel): PMODE 1 keeps them in the spare bytes behind its last mesh's packets
+    l.count = tri_slots ? (unsigned long long *)(l.tris + tri_slots * 3 + (meshes - 1) * PAIR_PAD) : (unsigned long long *)p;
     return l;
 }
 
@@ -1351,13 +1355,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     f3 avg_color = mk3(0.0f);
     auto close_sample = [&](f3 a) { avg_color = avg_color + a; }; // scene_kernels.cuh:171-176
     uint32_t n_ext = 0, n_shadow = 0; // wave totals (uniform)
-    // PMODE 1 at five waves per SIMD has no scalar registers to spare either: two loop-carried counters ended up in a VGPR
-    // lane that itself lived in scratch -- a load, a v_writelane and a store per iteration, 0.5 GB of writes per 1080p
-    // frame.  Its totals sit in LDS instead, one 64-bit add per iteration: {extension rays, shadow rays << 32} in the 32
-    // spare bytes behind the last mesh's packets (PAIR_PAD leaves them).
-    constexpr bool LDS_COUNT = (PMODE == 1) && (WG == 1);
-    unsigned long long *lds_count =
-        LDS_COUNT ? (unsigned long long *)(PL.tris + K.pair_tri_slots * 3 + (K.pair_meshes - 1) * PAIR_PAD) : nullptr;
+    // The pair modes have no scalar registers to spare: two loop-carried counters ended up in a VGPR lane that itself lived in
+    // scratch -- a load, a v_writelane and a store per iteration (0.5 GB of writes per 1080p Cornell frame at five waves per
+    // SIMD).  The totals sit in LDS instead, one 64-bit add per iteration: {extension rays, shadow rays << 32}.
+    constexpr bool LDS_COUNT = (PMODE >= 1) && (WG == 1);
+    unsigned long long *lds_count = LDS_COUNT ? PL.count : nullptr;
     if (LDS_COUNT) {
         if (lane == 0)
             *lds_count = 0ull;

@@ -579,7 +579,7 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
 // shadow pairs get what is left of a 10-KB LDS budget (16 waves per CU), at least 64 (one mesh per pass), at most
 // another 64 * meshes (everything in one pass)
 int merged_pair_cap(const ptrt_ctx *c) {
-    const size_t rest = (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
+    const size_t rest = (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16;
     const int lo = 64 * c->pair_meshes + 64, hi = 128 * c->pair_meshes;
     int cap = rest < 10240 ? (int)((10240 - rest) / 2) / 64 * 64 : 0;
     cap = cap < lo ? lo : cap;
@@ -588,15 +588,15 @@ int merged_pair_cap(const ptrt_ctx *c) {
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
     if (pmode == 4)
         return (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)merged_pair_cap(c) * 2 +
-               (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
+               (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16;
     if (pmode == 3) // no mesh table; pair list for one TLAS leaf per ray; TLAS stack + the rays' leaf starts
         return ((size_t)c->tlas_max_leaf * 64 + pt::TLAS_FILL_TARGET) * 2 + 512 * pt::TLAS_SLOTS +
                (size_t)c->stack_entries * 64 * sizeof(uint2) + (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 +
-               256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES;
+               256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES + 16;
     // staged heads (PMODE 1: and the mesh table), 16-bit pair entries, the rays' minima (whose second half holds the any-hit flags)
     const size_t common = (size_t)c->pair_meshes * (pmode == 1 ? 48 : 32) + (size_t)c->pair_meshes * 128 + 512;
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
-                      : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES;
+                      : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16; // (+ the ray totals)
 }
 // 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
 int pair_mode(const ptrt_ctx *c, int geom) {

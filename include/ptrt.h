@@ -372,7 +372,7 @@ int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);
 /* The body of Scene::render_to_device (scene.cuh:1028-1209): path_trace_kernel, then -- for
  * full-frame contexts that enabled them -- motion vectors + denoiser, bloom, up-scale, and the
  * tonemap of the final HDR image (fused into whichever stage produces it).  `frame_index` is the reference's frame_count_ (jitter index frame+s,
- * scene_kernels.cuh:152-157).  `out_rgb8`: tile_rows*W*3 bytes, bottom-up within
+ * scene_kernels.cuh:152-157; >= 0 -- a negative one is PTRT_E_INVALID: it would index the jitter table out of bounds).  `out_rgb8`: tile_rows*W*3 bytes, bottom-up within
  * the tile; a DEVICE pointer if out_is_device != 0 (the mapped PBO of
  * glfw_view_interop.hpp:281), else a host buffer (synchronous copy).  NULL skips
  * the copy (the RGB8 image stays readable through PTRT_BUF_RGB8).

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -1897,6 +1898,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         return fail(c, PTRT_E_NOT_READY, "ptrt_render: generator states not initialised (ptrt_reset_rng)");
     if (spp < 1 || max_depth < 1)
         return fail(c, PTRT_E_INVALID, "ptrt_render: spp=%d max_depth=%d", spp, max_depth);
+    if (frame_index < 0 || frame_index > INT_MAX - spp) // (sample s of the frame indexes the jitter table with (frame_index + s) % 16)
+        return fail(c, PTRT_E_INVALID, "ptrt_render: frame_index=%d", frame_index);
     if (int rc = set_device(c))
         return rc;
     pt::KParams K = make_params(c);

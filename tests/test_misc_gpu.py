@@ -83,6 +83,8 @@ def test_render_before_upload_and_bad_scenes(P):
     P.scenes.cornell(s)
     s.uploadToGPU()
     assert P.lib.ptrt_render(s.ctx, 0, 0, 4, None, 0) == -1          # spp < 1
+    assert P.lib.ptrt_render(s.ctx, -1, 1, 4, None, 0) == -1         # a negative frame index would index the jitter table out of bounds
+    assert P.lib.ptrt_render(s.ctx, 2**31 - 1, 4, 4, None, 0) == -1
     # a face index out of range is rejected at upload, not discovered by a faulting kernel
     d = s.flatten().contents
     bad = (P.Tri * 12)(*[P.Tri(0, 1, 99) for _ in range(12)])

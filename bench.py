@@ -140,14 +140,16 @@ class Farm:
         trows = tilefarm.max_strip_rows(H, world) if self.strips else self.rows  # (strip images are padded to one size)
         self.tiles = [torch.empty((trows, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
         self.views = [None, None]
-        self.frames = self.parts = self.index = None
+        self.frames = self.frames_ext = self.parts = self.assemblers = None
         if world > 1 and rank == 0:
             fdev = "cpu" if rehearse else "cuda"
-            self.frames = [torch.empty((H, W, 3), dtype=torch.uint8, device=fdev) for _ in range(2)]
+            # (one spare row behind the frame: where the strip layout's padding rows go, tilefarm.StripAssembler)
+            self.frames_ext = [torch.empty((H + 1, W, 3), dtype=torch.uint8, device=fdev) for _ in range(2)]
+            self.frames = [f[:H] for f in self.frames_ext]
             self.views = [tilefarm.frame_views(f, H, world) for f in self.frames]
             if self.strips:
-                self.parts = [[torch.empty((trows, W, 3), dtype=torch.uint8, device=fdev) for _ in range(world)] for _ in range(2)]
-                self.index = [torch.tensor(tilefarm.strip_frame_index(H, world, r), dtype=torch.long, device=fdev) for r in range(world)]
+                self.assemblers = [tilefarm.StripAssembler(torch, H, W, world, fdev) for _ in range(2)]
+                self.parts = [a.parts for a in self.assemblers]
         self.pending = [None, None]
         # --denoise / --bloom with N > 1 (not the headline): the bands send HDR + G-buffers (32 B/px) instead of RGB8
         # and rank 0 runs the post chain over the gathered frame in a second, full-frame context
@@ -200,10 +202,11 @@ class Farm:
         if self.strips:
             parts = self.parts[b] if rank == 0 else None
             if rehearse:
-                tf.gather_strips(self.dist, self.tiles[b].cpu(), self.frames[b] if rank == 0 else None, parts, self.index,
-                                 rank, world)
+                tf.gather_strips(self.dist, self.tiles[b].cpu(), None, parts, None, rank, world, async_op=True).wait()
+                if rank == 0:
+                    self.assemblers[b].scatter(self.frames_ext[b])
             else:
-                self.pending[b] = tf.gather_strips(self.dist, self.tiles[b], None, parts, self.index, rank, world, async_op=True)
+                self.pending[b] = tf.gather_strips(self.dist, self.tiles[b], None, parts, None, rank, world, async_op=True)
         elif rehearse:
             tf.gather_bands(self.dist, self.tiles[b].cpu(), self.views[b], rank, world, self.H)
         else:
@@ -215,7 +218,7 @@ class Farm:
             self.pending[b].wait()
             self.pending[b] = None
             if self.strips and self.env["rank"] == 0:
-                self.tilefarm.scatter_strips(self.frames[b], self.parts[b], self.index)
+                self.assemblers[b].scatter(self.frames_ext[b])
 
     def fence(self):
         for b in (0, 1):

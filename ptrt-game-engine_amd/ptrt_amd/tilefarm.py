@@ -61,6 +61,26 @@ def scatter_strips(frame, parts, index):
         frame.index_copy_(0, idx, parts[r][:idx.numel()])
 
 
+class StripAssembler:
+    """Rank 0's side of the strip layout with ONE copy kernel per frame: the ranks' (padded) strip images are gathered into
+    views of one (world * max_rows, W, 3) buffer, and one index_copy_ moves every row to its place in a frame that has one
+    spare row (index `height`) for the padding rows."""
+
+    def __init__(self, torch, height, width, world, device):
+        self.height, self.rows = height, max_strip_rows(height, world)
+        self.buf = torch.empty((world * self.rows, width, 3), dtype=torch.uint8, device=device)
+        self.parts = [self.buf[r * self.rows:(r + 1) * self.rows] for r in range(world)]
+        idx = []
+        for r in range(world):
+            fi = strip_frame_index(height, world, r)
+            idx += fi + [height] * (self.rows - len(fi))
+        self.index = torch.tensor(idx, dtype=torch.long, device=device)
+
+    def scatter(self, frame_ext):
+        """frame_ext: (height + 1, W, 3); rows [0, height) are the assembled frame afterwards."""
+        frame_ext.index_copy_(0, self.index, self.buf)
+
+
 def frame_views(frame, height, world):
     """Views into a (H, W, 3) uint8 frame, one per rank, where that rank's band image lands."""
     return [frame[height - (y0 + rows):height - y0] for (y0, rows) in bands(height, world)]

@@ -41,8 +41,14 @@ def _strip_worker(rank, world, port, out_path):
     parts = [torch.zeros((mx, W, 3), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
     index = [torch.tensor(tilefarm.strip_frame_index(H, world, r), dtype=torch.long) for r in range(world)]
     tilefarm.gather_strips(dist, tile, frame, parts, index, rank, world)
+    # the same through the one-kernel assembler bench.py uses (views of one buffer, a spare frame row for the padding)
+    asm = tilefarm.StripAssembler(torch, H, W, world, "cpu") if rank == 0 else None
+    ext = torch.zeros((H + 1, W, 3), dtype=torch.uint8) if rank == 0 else None
+    tilefarm.gather_strips(dist, tile, None, asm.parts if rank == 0 else None, None, rank, world, async_op=True).wait()
     dist.barrier()
     if rank == 0:
+        asm.scatter(ext)
+        assert torch.equal(ext[:H], frame)
         np.save(out_path, frame.numpy())
     dist.destroy_process_group()
 

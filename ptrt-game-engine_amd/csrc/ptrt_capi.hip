@@ -351,16 +351,10 @@ int convert_tree(const ptrt_bvh_node *in, int n_in, std::vector<float4> &out_nod
         return root;
     // Numbering: the top TOP_LEVELS levels in level order (a tree's first 2^TOP_LEVELS - 1 inner nodes are then its top
     // levels, which the LDS-staged variant of the trace kernel copies per workgroup), everything below depth first.
-    // (PTRT_BFS_LEVELS: how many levels are numbered in level order -- an experiment knob for the node layout)
-    static const int bfs_levels = [] {
-        const char *e = getenv("PTRT_BFS_LEVELS");
-        const int v = e ? atoi(e) : pt::TOP_LEVELS;
-        return v < pt::TOP_LEVELS ? pt::TOP_LEVELS : v;
-    }();
     size_t head = 0;
     while (head < work.size()) {
         Item it;
-        if (work[head].depth <= bfs_levels) { // (a node of the top levels: first in, first out)
+        if (work[head].depth <= pt::TOP_LEVELS) { // (a node of the top levels: first in, first out)
             it = work[head];
             ++head;
         } else {

@@ -443,7 +443,8 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   fetch_min 0..64       idle lanes before the pair queue refills     leaf_pairs 0|1  compacted leaf phase
  *   leaf_min 1..64        lanes waiting at a leaf that end the descent steal 0..64     shadow-ray subtree stealing
  *   lds_nodes 0|1         PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels
- *   merged 0|1            one traversal per loop iteration: a light sample's shadow ray rides with the next extension ray
+ *   merged -1|0|1         one traversal per loop iteration: a light sample's shadow ray rides with the next extension ray;
+ *                         -1 (default): both shapes take turns over a scene's frames 4-7 and the faster one stays (one host wait at frame 8)
  *   stage 0..7            PMODE 1: shading inputs kept in LDS (0 none; else jitter inputs, |1 light records, |2 material records)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)
  *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9

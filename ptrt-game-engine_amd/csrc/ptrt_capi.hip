@@ -163,7 +163,12 @@ struct ptrt_ctx {
     int stage = 7; // PMODE 1, shading inputs staged in LDS: 0 none, else jitter table + blue noise, | 1 lights, | 2 materials
     int lds_nodes = 0; // option: PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels (measured slower: DESIGN.md 3.1)
     int n_nodes = 0;
-    int merged = 0; // option: PMODE 4 (one traversal per loop iteration) where PMODE 2 applies; measured equal to PMODE 2 on the showcase frame, 10 % slower on the fluid frame
+    // option: PMODE 4 (one traversal per loop iteration) where PMODE 2 applies: 0 / 1, or -1 = try both on a scene's first
+    // frames and keep the faster (showcase: PMODE 4 by 1.5 %; fluid, 1 M triangles: PMODE 2 by 2-5 %; the bits are the same)
+    int merged = -1;
+    int merged_eff = 0;                  // what this launch uses
+    int tune_n = 0, tune_choice = -1;    // auto: frames measured so far (variants alternate), the decision (-1: none yet)
+    unsigned long long tune_key = ~0ull, tune_launch[4] = {0, 0, 0, 0};
     bool timed = false;
 };
 
@@ -611,7 +616,7 @@ int pair_mode(const ptrt_ctx *c, int geom) {
     if (geom == 0 && c->pair_meshes < 1024 && c->pair_max_leaf < 65536 && pair_lds_bytes(c, 1) <= 40 * 1024)
         return 1;
     // (PMODE 4's compacted leaf phase is not optional: scenes with leaves beyond its list keep PMODE 2)
-    if (geom <= 1 && c->merged && c->leaf_pairs && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) &&
+    if (geom <= 1 && c->merged_eff && c->leaf_pairs && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) &&
         (size_t)c->pair_max_leaf * 64 <= (size_t)pt::LEAF_PAIR_BYTES - 512 && pair_lds_bytes(c, 4) <= 40 * 1024)
         return 4;
     if (geom <= 1 && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) && pair_lds_bytes(c, 2) <= 40 * 1024)
@@ -1917,7 +1922,44 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const int grid = K.tiles_x * tiles_y;
     const int geom = pick_geom(c);
     const bool full = c->mats_full || c->force_full;
+    // merged = -1: the two exact shapes of the queue modes' loop (shadow rays in their own traversal, or riding with the next
+    // extension rays) take turns over a scene's frames 4-7 (the first four warm the clocks up); their kernel times (the event
+    // ring) decide the rest at frame 8, which waits for frame 7 once
+    bool tuning = false;
+    c->merged_eff = c->merged > 0 ? 1 : 0;
+    c->merged_eff = 1;
+    const bool merged_possible = pair_mode(c, geom) == 4; // (only the queue mode over BLASes has the merged shape)
+    c->merged_eff = c->merged > 0 ? 1 : 0;
+    if (c->merged < 0 && merged_possible) {
+        const unsigned long long key = ((((unsigned long long)c->n_geometry_uploads * 131 + (unsigned)spp) * 131 + (unsigned)max_depth) * 131 +
+                                        (unsigned)(c->steal * 64 + c->fetch_min)) * 131 + (unsigned)(c->leaf_min * 8 + c->leaf_pairs * 4 + c->lds_nodes * 2 + c->pair_trace);
+        if (key != c->tune_key) {
+            c->tune_key = key;
+            c->tune_n = 0;
+            c->tune_choice = -1;
+        }
+        if (c->tune_choice < 0 && c->tune_n < 8) { // frames 0-3 warm the clocks up; 4, 6 merged; 5, 7 separate
+            c->merged_eff = c->tune_n >= 4 && !(c->tune_n & 1);
+            tuning = true;
+        } else if (c->tune_choice < 0) { // frame 8: one host wait for frame 7, once per scene
+            float t[4] = {0, 0, 0, 0};
+            bool ok = c->launches - c->tune_launch[0] < (unsigned long long)EV_RING - 8 &&
+                      hipEventSynchronize(c->ev_ring[2 * (c->tune_launch[3] % EV_RING) + 1]) == hipSuccess;
+            for (int i = 0; i < 4 && ok; ++i)
+                ok = hipEventElapsedTime(&t[i], c->ev_ring[2 * (c->tune_launch[i] % EV_RING)], c->ev_ring[2 * (c->tune_launch[i] % EV_RING) + 1]) == hipSuccess;
+            (void)hipGetLastError();
+            c->tune_choice = (ok && std::min(t[0], t[2]) < std::min(t[1], t[3])) ? 1 : 0;
+            c->merged_eff = c->tune_choice;
+            if (getenv("PTRT_DEBUG_LDS"))
+                fprintf(stderr, "ptrt: merged loop %.3f / %.3f ms, separate %.3f / %.3f ms -> %s\n", t[0], t[2], t[1], t[3],
+                        c->tune_choice ? "merged" : "separate");
+        } else {
+            c->merged_eff = c->tune_choice;
+        }
+    }
     const int pmode = pair_mode(c, geom);
+    if (c->merged < 0 && pmode == 4)
+        K.steal = 0; // (the merged loop is at its best without shadow-ray subtree stealing: 3.98 vs 4.17 ms on the showcase frame)
     const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
     if (pmode == 3) { // (outside the timed kernel: a 136-thread copy)
         hipLaunchKernelGGL(pt::gather_tlas_heads_kernel, dim3((c->n_tlas_index + 63) / 64), dim3(64), 0, c->stream,
@@ -1990,6 +2032,11 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         launch_trace<2, 0>(c, K, full, grid, lds);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
+    if (tuning) {
+        if (c->tune_n >= 4)
+            c->tune_launch[c->tune_n - 4] = c->launches;
+        ++c->tune_n;
+    }
     c->launches++;
     c->timed = true;
     float *current = K.accum; // `current_image` of Scene::render_to_device (scene.cuh:1086)
@@ -2483,7 +2530,7 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
     } else if (n == "lds_nodes") // PMODE 2 in 4-wave workgroups with the BLAS top levels staged in LDS (A/B, tests)
         c->lds_nodes = value < 0 ? 0 : (value > 2 ? 2 : (int)value); // (2: the larger workgroups without reading the staged nodes)
     else if (n == "merged") // PMODE 4 instead of 2: shadow rays ride with the next extension rays (A/B, tests)
-        c->merged = value ? 1 : 0;
+        c->merged = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "leaf_pairs") // PMODE 2: 0 = every lane walks its own leaf (A/B, tests)
         c->leaf_pairs = value ? 1 : 0;
     else if (n == "lds_pad") { // extra bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy, tests)

@@ -219,6 +219,23 @@ def test_showcase_small(P, O, blue_noise):
     s.close()
 
 
+def test_loop_shape_chosen_by_measurement(P, O, blue_noise):
+    """merged = -1 (the default): the queue mode's two loop shapes take turns on a scene's frames 4-7 and the library keeps
+    the faster from frame 8 on -- eleven consecutive frames, whichever shape each one ran in, equal the oracle's."""
+    s = P.Scene(96, 64)
+    P.scenes.showcase(s, segments=12)
+    gpu, cpu = render_both(P, O, s, blue_noise, 2, 5, 11)
+    assert_frames_equal(gpu, cpu)
+    s.close()
+    s = P.Scene(80, 56)  # (another setting of the queue: its own choice)
+    P.scenes.showcase(s, segments=10)
+    s.set_option("steal", 2)
+    s.set_option("fetch_min", 32)
+    gpu, cpu = render_both(P, O, s, blue_noise, 1, 4, 9)
+    assert_frames_equal(gpu, cpu)
+    s.close()
+
+
 @pytest.mark.parametrize("merged", [1, 0, 2])
 @pytest.mark.parametrize("fetch_min,leaf_pairs,leaf_min,steal", [(0, 0, 64, 0), (1, 1, 1, 1), (16, 0, 8, 2), (16, 1, 8, 0),
                                                                  (16, 1, 4, 2), (48, 1, 64, 8), (64, 1, 24, 1)])

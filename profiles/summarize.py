@@ -15,8 +15,12 @@ for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
 for f in newest.values():
     agg = collections.defaultdict(list)
     meta = None
-    for r in csv.DictReader(open(f)):
-        if "path_trace" in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f)) if "path_trace" in r["Kernel_Name"]]
+    # (a scene whose loop shape is chosen by measurement launches two variants in its first frames: the one it settles on --
+    # the last one dispatched -- is the one that counts)
+    steady = rows[-1]["Kernel_Name"] if rows else None
+    for r in rows:
+        if r["Kernel_Name"] == steady:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
     for k, v in agg.items():

@@ -1930,7 +1930,15 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     c->merged_eff = 1;
     const bool merged_possible = pair_mode(c, geom) == 4; // (only the queue mode over BLASes has the merged shape)
     c->merged_eff = c->merged > 0 ? 1 : 0;
-    if (c->merged < 0 && merged_possible) {
+    bool capturing = false; // (a caller recording this stream into a hipGraph: no host wait, no choice -- the default shape)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess)
+            capturing = cs != hipStreamCaptureStatusNone;
+        else
+            (void)hipGetLastError();
+    }
+    if (c->merged < 0 && merged_possible && !capturing) {
         const unsigned long long key = ((((unsigned long long)c->n_geometry_uploads * 131 + (unsigned)spp) * 131 + (unsigned)max_depth) * 131 +
                                         (unsigned)(c->steal * 64 + c->fetch_min)) * 131 + (unsigned)(c->leaf_min * 8 + c->leaf_pairs * 4 + c->lds_nodes * 2 + c->pair_trace);
         if (key != c->tune_key) {

@@ -136,9 +136,28 @@ PT_DEV f3 cross(f3 a, f3 b) {
     return f3{fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))};
 }
 PT_DEV float length(f3 v) { return sqrt_ieee(dot(v, v)); }
+// v / |v|: sqrt_ieee and div3 under ONE guard.  A squared length in [2^-60, 2^60) puts the length in [2^-30, 2^30] -- inside
+// div3's divisor range -- and bounds every component by it; what is left to check is that no component is a tiny nonzero
+// number.  Everything else (zero vectors included: the reference returns 0 for them) takes the compiler's sqrtf and divisions.
+__device__ __attribute__((noinline)) f3 normalize_slow(f3 v) {
+    const float len = __builtin_sqrtf(dot(v, v));
+    return (len > 0) ? f3{v.x / len, v.y / len, v.z / len} : mk3(0.0f);
+}
 PT_DEV f3 normalize(f3 v) {
-    const float len = length(v);
-    return (len > 0) ? (v / len) : mk3(0.0f);
+    const float d = dot(v, v);
+    const float len = sqrt_core(d);
+    const float r0 = __builtin_amdgcn_rcpf(len);
+    const float r = fma_(fma_(-len, r0, 1.0f), r0, r0);
+    f3 q = f3{div3_core(v.x, len, r), div3_core(v.y, len, r), div3_core(v.z, len, r)};
+    const uint32_t lo = min(min(__float_as_uint(v.x) * 2u - 2u, __float_as_uint(v.y) * 2u - 2u), __float_as_uint(v.z) * 2u - 2u);
+    const bool ok = (__float_as_uint(d) - 0x21800000u) < (0x5d800000u - 0x21800000u) && lo >= (0x21800000u * 2u - 2u);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+        const f3 s = normalize_slow(v);
+        q.x = ok ? q.x : s.x;
+        q.y = ok ? q.y : s.y;
+        q.z = ok ? q.z : s.z;
+    }
+    return q;
 }
 // NaN-ignoring max/min with "second operand on ties" (matches the oracle's dm_max/dm_min)
 PT_DEV float max_(float a, float b) { return (a > b || b != b) ? a : b; }

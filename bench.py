@@ -89,13 +89,24 @@ def cpu_baseline(P, scene_name, W, H, spp, depth, frame, threads):
     rays, dt, y0 = sample(rows, threads)
     rows1 = max(8, rows // 16)
     rays1, dt1, y01 = sample(rows1, 1)
+    # every hardware thread this process may use (1-core AND all-core); a second frame's worth of rows
+    # when the first took under two seconds, so that thread start-up is not what is timed
+    allc = len(os.sched_getaffinity(0))
+    all_core = None
+    if allc > threads:
+        raysA, dtA, y0A = sample(rows, allc)
+        all_core = {"value": round(raysA / dtA / 1e6, 3), "unit": "Mrays/s", "cores": allc,
+                    "sample": f"rows {y0A}..{y0A + rows}, {raysA} rays in {dtA:.2f} s"}
     s.close()
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "host_cores": os.cpu_count(),
-            "sample": f"rows {y0}..{y0 + rows} of one {W}x{H} frame, {spp} spp, {depth} bounces, "
-                      f"{rays} rays in {dt:.2f} s", "fps_equivalent": round(rows / H / dt, 4) if rows else None,
-            "single_thread": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
-                              "sample": f"rows {y01}..{y01 + rows1}, {rays1} rays in {dt1:.2f} s"}}
+    out = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "host_cores": os.cpu_count(),
+           "sample": f"rows {y0}..{y0 + rows} of one {W}x{H} frame, {spp} spp, {depth} bounces, "
+                     f"{rays} rays in {dt:.2f} s", "fps_equivalent": round(rows / H / dt, 4) if rows else None,
+           "single_thread": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                             "sample": f"rows {y01}..{y01 + rows1}, {rays1} rays in {dt1:.2f} s"}}
+    if all_core:
+        out["all_core"] = all_core
+    return out
 
 
 class Farm:
@@ -232,6 +243,12 @@ class Farm:
         torch, env = self.torch, self.env
         for _ in range(warmup):
             self.step()
+        # a queue-mode scene samples both shapes of its loop on its first frames (ptrt_set_option "merged" = -1: frames 4-9,
+        # decision at frame 10, one host wait): those frames stay outside the timed region whatever --warmup says
+        self.tuning_frames = 0
+        while self.tuning_frames < 16 and not self.scene.get_option("merged_decided"):
+            self.step()
+            self.tuning_frames += 1
         self.fence()
         self.scene.stats()  # reset counters
         t0 = time.perf_counter()
@@ -240,16 +257,19 @@ class Farm:
         self.fence()
         dt = time.perf_counter() - t0
         st = self.scene.stats()
-        rays = float(st["extension_rays"] + st["shadow_rays"])
+        rays = float(st["extension_rays"] + st["shadow_rays_walked"])  # rays actually traced
+        rays_ref = float(st["extension_rays"] + st["shadow_rays"])     # rays the reference path traces
         kms = self.scene.kernel_ms_history(steps)
         kernel_ms = float(kms.mean()) if len(kms) else float("nan")
         if env["world"] > 1:
-            t = torch.tensor([dt, rays, kernel_ms], dtype=torch.float64, device="cpu" if env["rehearse"] else "cuda")
+            t = torch.tensor([dt, rays, kernel_ms, rays_ref], dtype=torch.float64, device="cpu" if env["rehearse"] else "cuda")
             tmax, tsum = t.clone(), t.clone()
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
             self.dist.all_reduce(tsum, op=self.dist.ReduceOp.SUM)
-            dt, rays, kernel_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
-        return dict(dt=dt, rays=rays, kernel_ms=kernel_ms, steps=steps)
+            dt, rays, kernel_ms, rays_ref = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tsum[3])
+        return dict(dt=dt, rays=rays, rays_ref=rays_ref, kernel_ms=kernel_ms, steps=steps, tuning_frames=self.tuning_frames,
+                    pmode=self.scene.get_option("pmode"), merged_eff=self.scene.get_option("merged_eff"),
+                    render_mode=self.scene.get_option("render_mode"))
 
     def close(self):
         self.scene.close()
@@ -258,16 +278,29 @@ class Farm:
         self.tiles = self.views = None
 
 
+def kernel_name(m):
+    """The kernel the timed frames ran, from what the library reports about its last launch (ptrt_get_option)."""
+    if m["render_mode"] == 1:
+        return "wf_trace_kernel + wf_shade_kernel (wavefront stages)"
+    if m["render_mode"] == 2:
+        return "path_trace_async_kernel (asynchronous lanes)"
+    shape = {0: "lock-step", 1: "pairs over LDS-staged triangles", 2: "pair queue, separate shadow phase",
+             3: "TLAS rounds", 4: "pair queue, shadow rays merged into the next traversal"}[m["pmode"]]
+    return f"path_trace_kernel PMODE {m['pmode']} ({shape}; megakernel, fused tonemap)"
+
+
 def roofline_block(config_name, kernel_ms, pixels):
     """HBM entry per the bench contract (algorithmic bytes / kernel time / peak) plus the bound that binds this path:
     VALU issue.  Instruction counts, lane occupancy and measured HBM traffic come from the committed profile summary
-    (profiles/summarize.py -> profiles/r02_roofline_inputs.json), the kernel time from this run's HIP events."""
+    (profiles/summarize.py -> profiles/rNN_roofline_inputs.json), the kernel time from this run's HIP events."""
     algo_bytes = ALGO_BYTES_PER_PIXEL * pixels
     ok = kernel_ms == kernel_ms and kernel_ms > 0
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if ok else None
     prof = {}
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_inputs.json"))).get(config_name, {})
+    try:  # the newest round's summary (profiles/summarize.py)
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_roofline_inputs.json")))[-1]
+        prof = json.load(open(newest)).get(config_name, {})
     except Exception:
         prof = {}
     valu = prof.get("valu_wave_instructions_per_launch")
@@ -398,13 +431,14 @@ def main():
         c = CONFIGS["showcase4k8"]
         n3 = max(2, min(args.steps, 6))
         f3 = Farm(P, torch, dist, tilefarm, env, c["scene"], c["width"], c["height"], c["spp"], c["depth"])
-        m3 = f3.measure(n3, 9)  # (9 warm-up frames: the showcase kernel picks its loop shape on frames 4-8)
+        m3 = f3.measure(n3, 9)  # (+ the frames on which the showcase kernel picks its loop shape: Farm.measure)
         part3 = "interleaved 8-row strip set(s)" if f3.strips else "band(s)"
         f3.close()
         c3 = {"workload": f"showcase {c['width']}x{c['height']} {c['spp']}spp {c['depth']}-bounce, {world} {part3}",
               "metric": "Mrays/s", "value": round(m3["rays"] / m3["dt"] / 1e6, 2), "n_gpus": world, "steps": n3, "warmup": 9,
               "ms_per_step": round(m3["dt"] / n3 * 1e3, 4), "fps": round(n3 / m3["dt"], 3), "scaling": "strong",
-              "rays_per_frame": round(m3["rays"] / n3), "kernel_ms_max_over_ranks": round(m3["kernel_ms"], 4)}
+              "rays_per_frame": round(m3["rays"] / n3), "kernel_ms_max_over_ranks": round(m3["kernel_ms"], 4),
+              "tuning_frames": m3["tuning_frames"], "kernel": kernel_name(m3)}
 
     if rank != 0:
         dist.destroy_process_group()
@@ -420,8 +454,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "fps": round(args.steps / dt, 2),
         "rays_per_frame": round(rays / args.steps),
-        "rays_note": "extension + shadow rays of the reference path (== the oracle's counts); a light sample whose value "
-                     "is exactly zero is counted but its shadow ray is not walked (DESIGN.md 3.1)",
+        "rays_reference_path": round(m["rays_ref"] / args.steps),
+        "rays_note": "value counts rays actually traced: extension rays + WALKED shadow rays (ptrt_stats.shadow_rays_walked; the "
+                     "oracle counts the same).  rays_reference_path also counts the light samples whose value is exactly zero: "
+                     "the reference sends a shadow ray for them, this kernel does not (DESIGN.md 3.1)",
         "config": {"workload": f"{cfg['scene']} {W}x{H} {spp_used}spp {depth_used}-bounce"
                                + (f" preset {args.preset}" if args.preset else "")
                                + (" +denoise" if args.denoise else "") + (" +bloom" if args.bloom else "")
@@ -429,7 +465,7 @@ def main():
                                + (" +gpu-rebuild" if args.rebuild else ""), "name": args.config, "scene": cfg["scene"],
                    "width": W, "height": H, "spp": spp_used, "max_depth": depth_used,
                    "parallelism": (f"tile{world}-{layout}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
-                   "kernel": "path_trace_kernel (megakernel, fused tonemap)"},
+                   "kernel": kernel_name(m), "tuning_frames": m["tuning_frames"], "library": P.library_info()},
         "roofline": roofline_block(profile_key if world == 1 else None, kernel_ms, W * rows0),
     }
     if c3 is not None:

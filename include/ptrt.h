@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTRT_ABI_VERSION 4 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height; 3: + ptrt_post_frame, ptrt_update_instances; 4: + ptrt_ring_*, ptrt_farm_* (additions only) */
+#define PTRT_ABI_VERSION 5 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height; 3: + ptrt_post_frame, ptrt_update_instances; 4: + ptrt_ring_*, ptrt_farm_* (additions only); 5: ptrt_stats gained shadow_rays_walked (the struct grew: rebuild callers of ptrt_get_stats) */
 
 enum {
     PTRT_OK = 0,
@@ -155,6 +155,11 @@ typedef struct ptrt_stats {
     uint64_t extension_rays; /* traceRay calls   (intersection.cuh:526) */
     uint64_t shadow_rays;    /* bvh_any_hit_tlas (intersection.cuh:481) */
     uint64_t paths;          /* pixel-samples started                   */
+    /* ABI 5.  shadow_rays counts every light sample the reference path sends a shadow ray for (path_logic.cuh:357);
+     * a sample whose value is exactly zero whatever its visibility (outside a spot cone, BSDF zero below the horizon)
+     * is counted there but its ray is NOT walked by path_trace_kernel.  shadow_rays_walked excludes those, so
+     * extension_rays + shadow_rays_walked = rays actually traced (SURVEY 8(d)'s Mrays/s numerator). */
+    uint64_t shadow_rays_walked;
 } ptrt_stats;
 
 #define PTRT_BLUE_NOISE_SIZE 64 /* common/bluenoise.cuh: 64 x 64 x 2 floats */
@@ -221,8 +226,10 @@ int ptrt_upload_geometry(ptrt_ctx *ctx, const ptrt_mesh_desc *meshes, int mesh_c
  * (scene.cuh:656-743) and of commitObjectChanges (scene.cuh:1784-1787): takes the new world / inverse /
  * normal matrices and has_transform flags of every mesh and the rebuilt TLAS; vertices, BLASes and triangle
  * packets on the device stay where they are (a full ptrt_upload_geometry re-lays-out every triangle).
- * mesh_count must equal the uploaded one; the other mesh fields are not read, and the meshes' root boxes on
- * the device (which a ptrt_refit / ptrt_build_bvh may have moved since the upload) are left alone. */
+ * mesh_count must equal the uploaded one.  Read from each descriptor: world, inverse, normal, has_transform -- nothing
+ * else (vertex, face and BVH pointers may be stale or NULL).  The meshes' root boxes on the device, which a ptrt_refit /
+ * ptrt_build_bvh may have moved since the upload, are left alone; the world-space first-pass boxes of the instances
+ * (scenes with a real TLAS) are recomputed from those DEVICE boxes (one small read-back; the call synchronises). */
 int ptrt_update_instances(ptrt_ctx *ctx, const ptrt_mesh_desc *meshes, int mesh_count,
                           const ptrt_bvh_node *tlas_nodes, int tlas_node_count,
                           const int32_t *tlas_mesh_indices, int tlas_index_count);
@@ -425,7 +432,9 @@ int ptrt_post_frame(ptrt_ctx *ctx, const float *accum, const float *normal, cons
  * them AFTER the farm); they must tile the frame exactly once, else PTRT_E_INVALID.
  *   ptrt_farm_render  = ptrt_render(ctx, frame, spp, depth, NULL, 0) on every context + ptrt_farm_gather
  *   ptrt_farm_gather  = gather of the images the contexts hold (for callers that render through the Scene mirror)
- *   ptrt_farm_transport: "device-copy" (all contexts on one device) or "rccl".  Errors: ptrt_last_error(NULL). */
+ *   ptrt_farm_transport: "device-copy" (all contexts on one device) or "rccl".  Errors: ptrt_last_error(NULL).
+ * The "rccl" transport is UNVERIFIED ON HARDWARE (every test so far ran on a one-GPU box).  A presentation-ring slot as the
+ * device target (rtgl::map_pbo_device_ptr) is recognised: its download is ordered behind the gather's copies. */
 typedef struct ptrt_farm ptrt_farm;
 int ptrt_farm_create(ptrt_ctx *const *contexts, int n_contexts, ptrt_farm **out);
 int ptrt_farm_bands(const ptrt_farm *farm);
@@ -444,12 +453,21 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   leaf_min 1..64        lanes waiting at a leaf that end the descent steal 0..64     shadow-ray subtree stealing
  *   lds_nodes 0|1         PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels
  *   merged -1|0|1         one traversal per loop iteration: a light sample's shadow ray rides with the next extension ray;
- *                         -1 (default): both shapes take turns over a scene's frames 4-7 and the faster one stays (one host wait at frame 8)
+ *                         -1 (default): both shapes (equal bit for bit) take turns over a scene's frames 4-9, three samples
+ *                         each; the merged one stays only if its median kernel time is at least 0.5 % below the separate-phase
+ *                         default's.  The decision, at frame 10, is the ONE place where the otherwise asynchronous ptrt_render
+ *                         blocks the host (a hipEventSynchronize on frame 9, once per scene and setting); set merged to 0 or 1
+ *                         before the first frame to opt out.  Never taken while the stream is being captured into a hipGraph.
  *   stage 0..7            PMODE 1: shading inputs kept in LDS (0 none; else jitter inputs, |1 light records, |2 material records)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)
  *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9
  *   denoiser_active, motion_vectors, use_graphs 0|1 */
 int ptrt_set_option(ptrt_ctx *ctx, const char *name, long long value);
+/* Reads an option back, and -- read-only -- what the last ptrt_render launched, so that a measurement can name the kernel it
+ * timed: render_mode (0 megakernel, 1 wavefront stages, 2 asynchronous lanes), pmode (0 lock-step, 1 pairs over LDS-staged
+ * triangles, 2 pair queue, 3 TLAS rounds, 4 merged queue), merged_eff (loop shape of that launch), merged_decided (0 while
+ * merged = -1 is still sampling), launches.  ABI 5. */
+int ptrt_get_option(ptrt_ctx *ctx, const char *name, long long *value);
 
 /* Render on a caller-owned HIP stream (a `hipStream_t` passed as void*; NULL returns to the
  * context's own stream).  Lets a host that already orders work on a stream (a GL-interop map,

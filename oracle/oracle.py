@@ -28,7 +28,8 @@ class RenderArgs(C.Structure):
                 ("blue_noise", C.POINTER(C.c_float)), ("rng", C.POINTER(C.c_uint32)),
                 ("accum", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)), ("depth", C.POINTER(C.c_float)),
                 ("object_id", C.POINTER(C.c_int32)),
-                ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64)]
+                ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
+                ("shadow_rays_walked", C.c_uint64)]
 
 
 _fp = C.POINTER(C.c_float)
@@ -98,11 +99,12 @@ def render(scene_desc_ptr, width, height, spp, max_depth, frame_count, blue_nois
                depth=np.zeros(n, np.float32), object_id=np.zeros(n, np.int32))
     a = RenderArgs(width, height, tile_y0, rows, spp, max_depth, frame_count, threads, _f(bn), _u(rng),
                    _f(out["accum"]), _f(out["normal"]), _f(out["depth"]),
-                   out["object_id"].ctypes.data_as(C.POINTER(C.c_int32)), 0, 0, 0)
+                   out["object_id"].ctypes.data_as(C.POINTER(C.c_int32)), 0, 0, 0, 0)
     rc = lib.oracle_render(C.cast(scene_desc_ptr, C.c_void_p), C.byref(a))
     if rc != 0:
         raise RuntimeError(f"oracle_render failed ({rc}); -2 means the CPU lacks FMA")
-    out["stats"] = dict(extension_rays=a.extension_rays, shadow_rays=a.shadow_rays, paths=a.paths)
+    out["stats"] = dict(extension_rays=a.extension_rays, shadow_rays=a.shadow_rays, paths=a.paths,
+                        shadow_rays_walked=a.shadow_rays_walked)
     return out
 
 

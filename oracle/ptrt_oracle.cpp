@@ -331,6 +331,9 @@ inline V3 transformNormal(const float *m, const V3 &n) { return normalize(transf
 
 struct Counters {
     uint64_t extension = 0, shadow = 0, paths = 0;
+    // light samples whose value is exactly zero whatever their visibility (bookkeeping for the kernel's "counted, not
+    // walked" shadow rays; the reference traces them like any other and nothing here depends on the count)
+    uint64_t shadow_zero = 0;
 };
 
 // intersection.cuh:300-341
@@ -1022,6 +1025,15 @@ V3 sample_direct_lighting_with_mat(const HitInfo &hit, const MaterialProps &mat,
     V3 shadow_offset = dot(hit.normal, L) > 0.0f ? hit.normal * 1e-4f : -hit.normal * 1e-4f;
     Ray shadowRay(hit.point + shadow_offset, L);
     bool inShadow = bvh_any_hit_tlas(shadowRay, light_dist - 1e-3f, S, cnt);
+    { // the same expression as below, evaluated for EVERY sample, only to count the ones that add nothing either way
+        bool nonzero = false;
+        if (pdf_sample > 0.0f) {
+            V3 d0 = clamp_vector_soft(evaluateBSDF(hit, mat, L, V) * light_radiance * attenuation / pdf_sample, 500.0f);
+            nonzero = d0.x > 0.0f || d0.y > 0.0f || d0.z > 0.0f;
+        }
+        if (!nonzero)
+            cnt.shadow_zero++;
+    }
     if (!inShadow) {
         V3 bsdf = evaluateBSDF(hit, mat, L, V);
         if (pdf_sample > 0.0f) {
@@ -1508,6 +1520,7 @@ struct oracle_render_args {
     float *depth;                 /* out: tile_rows*width                        */
     int32_t *object_id;           /* out: tile_rows*width                        */
     uint64_t extension_rays, shadow_rays, paths; /* out */
+    uint64_t shadow_rays_walked; /* out: shadow_rays minus the light samples whose value is exactly zero (ptrt.h ptrt_stats) */
 };
 
 int oracle_has_fma(void) { return __builtin_cpu_supports("fma") ? 1 : 0; }
@@ -1599,11 +1612,12 @@ int oracle_render(const ptrt_scene_desc *scene, oracle_render_args *a) {
                 a->rng[i * 6 + 1 + k] = rng.v[k];
         }
     });
-    a->extension_rays = a->shadow_rays = a->paths = 0;
+    a->extension_rays = a->shadow_rays = a->paths = a->shadow_rays_walked = 0;
     for (auto &c : cnt) {
         a->extension_rays += c.extension;
         a->shadow_rays += c.shadow;
         a->paths += c.paths;
+        a->shadow_rays_walked += c.shadow - c.shadow_zero;
     }
     return 0;
 }

@@ -8,6 +8,10 @@
 //   pathtracer/scene/lights.cuh:12-22    Light (layout the C ABI's ptrt_light mirrors)
 //   common/vec3.cuh, common/ray.cuh      vec3 / Ray layout, vec3's host-side arithmetic (known answers)
 //   common/matrix.cuh:8-90               mat3: the 3x3 products of the ACES tonemap (render_utils.cuh:77-95)
+//   common/vec4.cuh:13-122               vec4: layout, constructors, operators (`/` multiplies by the reciprocal), dot, length
+//   common/triangle.cuh:15-92            Triangle: the input type of Scene::addTriangles -- layout, constructor (e1, e2, n),
+//                                        normal, area, bounds, the two-sided intersect of the old intersection code
+// With these the curand-free headers of the reference are exhausted.
 //
 // Everything else on the path includes <curand_kernel.h> (pathtracer/math/mathutils.cuh:11, pulled
 // in by common/mat4.cuh:6), which the image lacks, so it is unbuildable here and stays
@@ -20,6 +24,8 @@
 #include "common/ray.cuh"
 #include "common/bluenoise.cuh"
 #include "common/matrix.cuh"
+#include "common/vec4.cuh"
+#include "common/triangle.cuh"
 #include "pathtracer/rendering/taa.cuh"
 #include "pathtracer/scene/lights.cuh"
 
@@ -107,6 +113,46 @@ int main(int argc, char **argv) {
         printf("],\"ai\":[");
         for (int i = 0; i < 9; ++i) printf("%s%u", i ? "," : "", bits(ai.m[i / 3][i % 3]));
         printf("]}");
+    }
+    printf("],\n");
+    // common/vec4.cuh on 24 seeded pairs; common/triangle.cuh on 32 seeded triangles, each with a ray aimed at a point of its
+    // plane (inside for most, outside for some) so that both outcomes of intersect occur
+    printf(" \"layout4\": {\"vec4\": %zu, \"vec4.w\": %zu, \"Triangle\": %zu, \"Triangle.v1\": %zu, \"Triangle.e1\": %zu, "
+           "\"Triangle.e2\": %zu, \"Triangle.n\": %zu},\n",
+           sizeof(vec4), offsetof(vec4, w), sizeof(Triangle), offsetof(Triangle, v1), offsetof(Triangle, e1), offsetof(Triangle, e2),
+           offsetof(Triangle, n));
+    printf(" \"vec4_kat\": [");
+    for (int k = 0; k < 24; ++k) {
+        const float ax = rnd(), ay = rnd(), az = rnd(), aw = rnd(), bx = rnd(), by = rnd(), bz = rnd(), bw = rnd(), t = rnd();
+        const vec4 a(ax, ay, az, aw), b(vec3(bx, by, bz), bw);
+        vec4 c = a;
+        c += b;
+        c *= t;
+        c -= a;
+        c /= bw;
+        const vec4 q = (a + b) * t - b / aw + t * (-a), nn = normalize(b);
+        const vec3 xyz = b.xyz();
+        printf("%s[%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u]", k ? "," : "", bits(dot(a, b)), bits(length(a)), bits(c.x),
+               bits(c.y), bits(c.z), bits(c.w), bits(q.x), bits(q.y), bits(q.z), bits(q.w), bits(nn.x), bits(nn.y), bits(nn.z), bits(nn.w),
+               bits(xyz.x), bits(xyz.y), bits(xyz.z), bits(b[3]), bits(vec4(t)[2]));
+    }
+    printf("],\n \"triangle_kat\": [");
+    for (int k = 0; k < 32; ++k) {
+        float f[14];
+        for (float &x : f) x = rnd(); // (in this order)
+        const vec3 v0(f[0], f[1], f[2]), v1(f[3], f[4], f[5]), v2(f[6], f[7], f[8]), o(f[9], f[10], f[11] + 9.0f);
+        const float wu = f[12] * 0.16f + 0.3f, wv = f[13] * 0.16f + 0.3f; // barycentrics in (-0.34, 0.94): some rays miss
+        const Triangle T(v0, v1, v2);
+        const vec3 target = v0 + wu * T.e1 + wv * T.e2, d = normalize(target - o);
+        vec3 bmin, bmax;
+        T.bounds(bmin, bmax);
+        float t = 0.0f, u = 0.0f, v = 0.0f;
+        const bool hit = T.intersect(Ray(o, d), t, u, v);
+        const vec3 nrm = T.normal();
+        printf("%s[%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%d,%u,%u,%u]", k ? "," : "", bits(T.e1.x), bits(T.e1.y),
+               bits(T.e1.z), bits(T.e2.x), bits(T.e2.y), bits(T.e2.z), bits(T.n.x), bits(T.n.y), bits(T.n.z), bits(nrm.x), bits(nrm.y),
+               bits(nrm.z), bits(T.area()), bits(bmin.x), bits(bmin.y), bits(bmin.z), bits(bmax.x), bits(bmax.y), bits(bmax.z), hit ? 1 : 0,
+               hit ? bits(t) : 0u, hit ? bits(u) : 0u, hit ? bits(v) : 0u);
     }
     printf("]\n}\n");
     return 0;

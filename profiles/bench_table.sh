@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU box, repo root: the rows of DESIGN.md section 6's tables -> gpurun_out/table_r02.txt
-O=gpurun_out/table_r02.txt; : > $O
+# GPU box, repo root: the rows of DESIGN.md section 6's tables -> gpurun_out/table.txt
+O=gpurun_out/table.txt; : > $O
 run() { echo "## $*" >> $O; python bench.py --no-cpu-baseline --no-configs3 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d.get('fps'), d['value'])" >> $O; }
 run --config cornell1080
 run --config showcase1080

@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU box, repo root: the profile set of a round (RND, default r03) (kernel stats + PMC passes per config, lane occupancy of the instrumented
+# build).  Afterwards, in the build container:  for c in cornell1080 showcase1080 fluid many; do
+#   python profiles/summarize.py $c r03 $c; done   and   cp gpurun_out/prof_lane/lane_occupancy.txt profiles/r03_lane_occupancy.txt
+R=$PWD; V=ptrt-game-engine_amd/build/variants
+CFGS=${1:-"cornell1080 showcase1080 fluid many"}
+mkdir -p gpurun_out/prof_lane
+for c in $CFGS; do
+  if [ $c = many ]; then bash profiles/pmc_pass.sh many --scene many; else bash profiles/pmc_pass.sh $c --config $c; fi
+  echo "pmc $c done"
+done
+cd $R
+( for c in "cornell1080:cornell 1920 1080 4" "showcase1080:showcase 1920 1080 4" "fluid:fluid 1920 1080 2" "many:many 1920 1080 4"; do echo "### ${c%%:*}"; PTRT_AMD_LIB=$V/libptrt_stats.so python tools/trav_stats.py ${c#*:}; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/prof_lane/lane_occupancy.txt
+tail -5 gpurun_out/prof_lane/lane_occupancy.txt

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
             c += __shfl_xor(c, off);
         }
         if (lane == 0) { // one slot per workgroup (the grid never exceeds the number of tiles)
-            unsigned long long *w = K.counters + (size_t)blockIdx.x * 3;
+            unsigned long long *w = K.counters + (size_t)blockIdx.x * COUNTER_WORDS; // (this shape walks every shadow ray: word 3 stays 0)
             w[0] += (unsigned long long)a;
             w[1] += (unsigned long long)b;
             w[2] += (unsigned long long)c;

@@ -105,8 +105,9 @@ struct KParams {
     float *accum, *normal, *depth;
     int *object_id;
     unsigned char *rgb8;
-    unsigned long long *counters; // {extension, shadow, paths} or nullptr
+    unsigned long long *counters; // COUNTER_WORDS per slot: {extension, shadow, paths, zero-valued light samples} or nullptr
 };
+constexpr int COUNTER_WORDS = 4;
 
 // frame row of a context's local row: contiguous rows from y0, or every il_period-th 8-row strip from strip il_phase
 PT_DEV int global_row(int yl, int y0, int il_period, int il_phase) {

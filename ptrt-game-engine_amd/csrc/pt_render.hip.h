@@ -59,7 +59,8 @@ struct PairLds {
     const float2 *bn;         // 64: the lanes' blue-noise values
     const float4 *lights;     // the scene's light records (4 float4 each) when at most LDS_LIGHTS of them
     const float4 *mats;       // PMODE 1: material records (6 float4) of the leaf's meshes by mesh order
-    unsigned long long *count; // one-wave workgroups: {extension rays, shadow rays << 32} of the wave so far
+    unsigned long long *count; // one-wave workgroups: [0] {extension rays, shadow rays << 32} of the wave so far, [1] light
+                               // samples whose value was exactly zero (counted in [0], not walked)
 };
 constexpr int LDS_LIGHTS = 8;
 constexpr int LDS_EXTRA_FIXED = 16 * 8 + 64 * 8; // jitter table + blue-noise values
@@ -1354,7 +1355,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     }
     f3 avg_color = mk3(0.0f);
     auto close_sample = [&](f3 a) { avg_color = avg_color + a; }; // scene_kernels.cuh:171-176
-    uint32_t n_ext = 0, n_shadow = 0; // wave totals (uniform)
+    uint32_t n_ext = 0, n_shadow = 0, n_zero = 0; // wave totals (uniform)
     // The pair modes have no scalar registers to spare: two loop-carried counters ended up in a VGPR lane that itself lived in
     // scratch -- a load, a v_writelane and a store per iteration (0.5 GB of writes per 1080p Cornell frame at five waves per
     // SIMD).  The totals sit in LDS instead, one 64-bit add per iteration: {extension rays, shadow rays << 32}.
@@ -1362,7 +1363,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     unsigned long long *lds_count = LDS_COUNT ? PL.count : nullptr;
     if (LDS_COUNT) {
         if (lane == 0)
-            *lds_count = 0ull;
+            lds_count[0] = lds_count[1] = 0ull;
         wave_sync();
     }
 
@@ -1630,6 +1631,21 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             }
         }
 
+        // (SURVEY 8(d) counts rays actually traced: the samples of [C] that are not walked are counted apart -- rare, so
+        // the LDS add sits behind a wave-uniform branch)
+        {
+            const unsigned long long zm = __builtin_amdgcn_ballot_w64(want_shadow && !lit);
+            if (zm) {
+                if (LDS_COUNT) {
+                    if (lane == 0)
+                        __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long *)(lds_count + 1),
+                                               (unsigned long long)__builtin_popcountll(zm), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    n_zero += (uint32_t)__builtin_popcountll(zm);
+                }
+            }
+        }
         if (PMODE == 1)
             TS_ADD(10, t_pc2);
         PT_MARK("D");
@@ -1753,21 +1769,23 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     if (K.counters) {
         if (LDS_COUNT) {
             wave_sync();
-            const unsigned long long t = *lds_count;
+            const unsigned long long t = lds_count[0];
             n_ext = (uint32_t)t;
             n_shadow = (uint32_t)(t >> 32);
+            n_zero = (uint32_t)lds_count[1];
         }
         const uint32_t a = n_ext, b = n_shadow,
                        c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside)) * (uint32_t)K.spp;
-        // one slot of three counters per workgroup, plain read-modify-write (only this workgroup touches
+        // one slot of four counters per workgroup, plain read-modify-write (only this workgroup touches
         // it within a launch; launches are ordered).  Three atomics per wave on three shared addresses
         // serialised at the L2 atomic unit: 97 K of them took 1.2 ms per 1080p frame -- hidden behind a
         // 2.7-ms trace, but the whole cost of a light frame (1 spp, 1 bounce: 1.19 ms -> 0.17 ms).
         if (lane == 0) {
-            unsigned long long *w = K.counters + (size_t)tile * 3;
+            unsigned long long *w = K.counters + (size_t)tile * COUNTER_WORDS;
             w[0] += (unsigned long long)a;
             w[1] += (unsigned long long)b;
             w[2] += (unsigned long long)c;
+            w[3] += (unsigned long long)n_zero;
         }
     }
 }

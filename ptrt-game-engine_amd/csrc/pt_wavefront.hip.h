@@ -272,7 +272,7 @@ template <bool FULL> __global__ __launch_bounds__(256) void wf_shade_kernel(cons
     const int lane = threadIdx.x & 63;
     const bool first = W.iter == 0;
     const size_t N = (size_t)W.n_items;
-    uint32_t n_ext = 0, n_shadow = 0, n_paths = 0;
+    uint32_t n_ext = 0, n_shadow = 0, n_paths = 0, n_zero = 0;
     bool alive_after = false;
     if (q < W.n_items) {
         const int tile = q >> 6, l = q & 63;
@@ -430,14 +430,18 @@ template <bool FULL> __global__ __launch_bounds__(256) void wf_shade_kernel(cons
                                     flags |= WF_PVALID;
                                 }
                             }
-                            W.sh[q] = shadow_o.x;
-                            W.sh[N + q] = shadow_o.y;
-                            W.sh[2 * N + q] = shadow_o.z;
-                            W.sh[3 * N + q] = L.x;
-                            W.sh[4 * N + q] = L.y;
-                            W.sh[5 * N + q] = L.z;
-                            W.sh[6 * N + q] = shadow_tmax;
-                            flags |= WF_SHADOW;
+                            if (flags & WF_PVALID) { // (a sample that adds nothing either way is counted, not walked)
+                                W.sh[q] = shadow_o.x;
+                                W.sh[N + q] = shadow_o.y;
+                                W.sh[2 * N + q] = shadow_o.z;
+                                W.sh[3 * N + q] = L.x;
+                                W.sh[4 * N + q] = L.y;
+                                W.sh[5 * N + q] = L.z;
+                                W.sh[6 * N + q] = shadow_tmax;
+                                flags |= WF_SHADOW;
+                            } else {
+                                ++n_zero;
+                            }
                         }
                         f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
                         bool is_specular = false;
@@ -572,17 +576,19 @@ template <bool FULL> __global__ __launch_bounds__(256) void wf_shade_kernel(cons
     if (__builtin_amdgcn_ballot_w64(alive_after) && lane == 0)
         W.live[W.iter] = 1u; // same value from every writer
     if (K.counters) {
-        uint32_t a = n_ext, b = n_shadow, c = n_paths;
+        uint32_t a = n_ext, b = n_shadow, c = n_paths, z = n_zero;
         for (int off = 32; off > 0; off >>= 1) {
             a += __shfl_xor(a, off);
             b += __shfl_xor(b, off);
             c += __shfl_xor(c, off);
+            z += __shfl_xor(z, off);
         }
         if (lane == 0 && (a | b | c)) { // one slot per wave of this grid; launches are ordered
-            unsigned long long *w = K.counters + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 3;
+            unsigned long long *w = K.counters + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * COUNTER_WORDS;
             w[0] += (unsigned long long)a;
             w[1] += (unsigned long long)b;
             w[2] += (unsigned long long)c;
+            w[3] += (unsigned long long)z;
         }
     }
 }

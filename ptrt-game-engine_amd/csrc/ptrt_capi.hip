@@ -31,6 +31,10 @@
 namespace {
 
 constexpr int EV_RING = 256;
+// loop-shape choice of the queue modes (ptrt_set_option "merged" = -1): frames that only warm the clocks up, samples per
+// shape (odd: their median decides), and the gain the merged loop must show to replace the separate-phase default
+constexpr int TUNE_WARM = 4, TUNE_SAMPLES = 3;
+constexpr float TUNE_MIN_GAIN = 0.005f;
 thread_local std::string g_last_error = "";
 std::mutex g_live_mutex;
 std::set<ptrt_ctx *> g_live;
@@ -53,7 +57,7 @@ struct ptrt_ctx {
     int *d_object_id = nullptr;
     unsigned char *d_rgb8 = nullptr;
     unsigned char *last_rgb8 = nullptr; // where the last frame's RGB8 went
-    unsigned long long *d_counters = nullptr; // n_counter_slots x {extension rays, shadow rays, paths}
+    unsigned long long *d_counters = nullptr; // n_counter_slots x pt::COUNTER_WORDS {extension rays, shadow rays, paths, zero-valued light samples}
     size_t n_counter_slots = 0;
     float2 *d_blue = nullptr;
     uint32_t *d_jump = nullptr;
@@ -168,7 +172,8 @@ struct ptrt_ctx {
     int merged = -1;
     int merged_eff = 0;                  // what this launch uses
     int tune_n = 0, tune_choice = -1;    // auto: frames measured so far (variants alternate), the decision (-1: none yet)
-    unsigned long long tune_key = ~0ull, tune_launch[4] = {0, 0, 0, 0};
+    unsigned long long tune_key = ~0ull, tune_launch[2 * TUNE_SAMPLES] = {};
+    int last_pmode = 0;                  // PMODE of the last megakernel launch (ptrt_get_option "pmode")
     bool timed = false;
 };
 
@@ -605,7 +610,7 @@ size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16; // (+ the ray totals)
 }
 // 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
-int pair_mode(const ptrt_ctx *c, int geom) {
+int pair_mode(const ptrt_ctx *c, int geom, bool merged) {
     if (!c->pair_trace)
         return 0;
     if (geom == 2) // a real TLAS: rounds of one leaf per ray (pt_render.hip.h)
@@ -616,7 +621,7 @@ int pair_mode(const ptrt_ctx *c, int geom) {
     if (geom == 0 && c->pair_meshes < 1024 && c->pair_max_leaf < 65536 && pair_lds_bytes(c, 1) <= 40 * 1024)
         return 1;
     // (PMODE 4's compacted leaf phase is not optional: scenes with leaves beyond its list keep PMODE 2)
-    if (geom <= 1 && c->merged_eff && c->leaf_pairs && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) &&
+    if (geom <= 1 && merged && c->leaf_pairs && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) &&
         (size_t)c->pair_max_leaf * 64 <= (size_t)pt::LEAF_PAIR_BYTES - 512 && pair_lds_bytes(c, 4) <= 40 * 1024)
         return 4;
     if (geom <= 1 && c->pair_meshes < 256 && c->pair_tri_slots < (1 << 24) && pair_lds_bytes(c, 2) <= 40 * 1024)
@@ -1065,14 +1070,14 @@ int create_ctx(int full_w, int full_h, int tile_y0, int tile_rows, int il_period
     HIP_TRY(c, hipMalloc((void **)&c->d_depth, c->npix * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_object_id, c->npix * sizeof(int)));
     HIP_TRY(c, hipMalloc((void **)&c->d_rgb8, c->npix * 3));
-    c->n_counter_slots = (size_t)((c->W + 7) / 8) * ((c->rows + 7) / 8); // one slot of 3 per 8x8-pixel workgroup
+    c->n_counter_slots = (size_t)((c->W + 7) / 8) * ((c->rows + 7) / 8); // one slot of pt::COUNTER_WORDS per 8x8-pixel workgroup
     c->n_counter_slots += 4; // the shade stage uses one slot per wave of a 256-thread grid (rounded up)
-    HIP_TRY(c, hipMalloc((void **)&c->d_counters, c->n_counter_slots * 3 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_counters, c->n_counter_slots * pt::COUNTER_WORDS * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc((void **)&c->d_blue, PTRT_BLUE_NOISE_FLOATS * sizeof(float)));
     HIP_TRY(c, hipMemsetAsync(c->d_rng, 0, c->npix * 6 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, c->npix * 3 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_rgb8, 0, c->npix * 3, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, c->n_counter_slots * 3 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, c->n_counter_slots * pt::COUNTER_WORDS * sizeof(unsigned long long), c->stream));
     // the blue-noise table is all zeros until the application installs one (bluenoise.cuh:46,189)
     HIP_TRY(c, hipMemsetAsync(c->d_blue, 0, PTRT_BLUE_NOISE_FLOATS * sizeof(float), c->stream));
     c->last_rgb8 = c->d_rgb8;
@@ -1181,7 +1186,7 @@ int ptrt_reset_rng(ptrt_ctx *c, unsigned long long seed) {
     return PTRT_OK;
 }
 
-int upload_instance_pretests(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count);
+int upload_instance_pretests(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count, const float4 *device_recs = nullptr);
 
 int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count, const ptrt_bvh_node *tlas_nodes,
                          int tlas_node_count, const int32_t *tlas_mesh_indices, int tlas_index_count) {
@@ -1397,14 +1402,16 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
 // that length); mapped back to world space that is at most |A^-1|_2 eta <= 2e-6 |A^-1|_F (|A|_F |o| + |t| + |box|), and
 // the world test's own rounding is below 1e-6 (|W| + |o|): Kc leaves a factor of 50.  A singular or non-finite A gets
 // an infinite box (every ray is a candidate: the local test decides, as before).
-int upload_instance_pretests(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count) {
+// `device_recs`: the mesh records as the DEVICE holds them now (root boxes moved by ptrt_refit / ptrt_build_bvh included); when
+// given, the local boxes come from there and the descriptors' BVH arrays are not read.
+int upload_instance_pretests(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_count, const float4 *device_recs) {
     std::vector<float4> pre((size_t)mesh_count * 2, f4(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f));
     double c2max = 0.0;
     const double Kc = 1e-4, BIG = 3.0e38;
     for (int m = 0; m < mesh_count; ++m) {
         const ptrt_mesh_desc &M = meshes[m];
         pre[(size_t)m * 2 + 1] = f4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);
-        if (!M.has_transform || !M.nodes || M.node_count <= 0)
+        if (!M.has_transform || (!device_recs && (!M.nodes || M.node_count <= 0)))
             continue;
         double A[3][3], t[3];
         for (int r = 0; r < 3; ++r) {
@@ -1434,8 +1441,14 @@ int upload_instance_pretests(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh
             nA = std::sqrt(nA);
             nI = std::sqrt(nI);
         }
-        const ptrt_bvh_node &rn = M.nodes[0];
-        const double lo[3] = {rn.bmin.x, rn.bmin.y, rn.bmin.z}, hi[3] = {rn.bmax.x, rn.bmax.y, rn.bmax.z};
+        double lo[3], hi[3];
+        if (device_recs) {
+            const float4 a = device_recs[(size_t)m * pt::MESH_REC_F4], b = device_recs[(size_t)m * pt::MESH_REC_F4 + 1];
+            lo[0] = a.x, lo[1] = a.y, lo[2] = a.z, hi[0] = b.x, hi[1] = b.y, hi[2] = b.z;
+        } else {
+            const ptrt_bvh_node &rn = M.nodes[0];
+            lo[0] = rn.bmin.x, lo[1] = rn.bmin.y, lo[2] = rn.bmin.z, hi[0] = rn.bmax.x, hi[1] = rn.bmax.y, hi[2] = rn.bmax.z;
+        }
         double wmin[3] = {BIG, BIG, BIG}, wmax[3] = {-BIG, -BIG, -BIG}, boxn = 0.0, tn = 0.0, wn = 0.0;
         for (int k = 0; k < 3; ++k) {
             const double a = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
@@ -1516,8 +1529,13 @@ int ptrt_update_instances(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_co
         return rc;
     drop_graphs(c);
     c->n_instance_updates++;
-    // (the caller's descriptors carry the current root boxes: the Scene mirror refits its host copy with the device's)
-    if (int rc = upload_instance_pretests(c, meshes, mesh_count))
+    // First-pass boxes of the instances (PMODE 3) from the root boxes the DEVICE holds: after a ptrt_refit / ptrt_build_bvh
+    // the caller's descriptors may describe the tree as it was uploaded (or BVH arrays that no longer exist), and a box
+    // built from a stale root would cull instances the reference's local test hits.  The descriptors' BVH arrays are not read.
+    std::vector<float4> dev_recs((size_t)mesh_count * pt::MESH_REC_F4);
+    HIP_TRY(c, hipMemcpyAsync(dev_recs.data(), c->d_mesh_recs, dev_recs.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = upload_instance_pretests(c, meshes, mesh_count, dev_recs.data()))
         return rc;
     return PTRT_OK;
 }
@@ -1926,9 +1944,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // extension rays) take turns over a scene's frames 4-7 (the first four warm the clocks up); their kernel times (the event
     // ring) decide the rest at frame 8, which waits for frame 7 once
     bool tuning = false;
-    c->merged_eff = c->merged > 0 ? 1 : 0;
-    c->merged_eff = 1;
-    const bool merged_possible = pair_mode(c, geom) == 4; // (only the queue mode over BLASes has the merged shape)
+    const bool merged_possible = pair_mode(c, geom, true) == 4; // (only the queue mode over BLASes has the merged shape)
     c->merged_eff = c->merged > 0 ? 1 : 0;
     bool capturing = false; // (a caller recording this stream into a hipGraph: no host wait, no choice -- the default shape)
     {
@@ -1946,26 +1962,35 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
             c->tune_n = 0;
             c->tune_choice = -1;
         }
-        if (c->tune_choice < 0 && c->tune_n < 8) { // frames 0-3 warm the clocks up; 4, 6 merged; 5, 7 separate
-            c->merged_eff = c->tune_n >= 4 && !(c->tune_n & 1);
+        if (c->tune_choice < 0 && c->tune_n < TUNE_WARM + 2 * TUNE_SAMPLES) { // warm-up frames, then merged / separate in turns
+            c->merged_eff = c->tune_n >= TUNE_WARM && !((c->tune_n - TUNE_WARM) & 1);
             tuning = true;
-        } else if (c->tune_choice < 0) { // frame 8: one host wait for frame 7, once per scene
-            float t[4] = {0, 0, 0, 0};
+        } else if (c->tune_choice < 0) { // the frame after the last sample: ONE host wait for that sample, once per scene and setting
+            float t[2 * TUNE_SAMPLES] = {};
             bool ok = c->launches - c->tune_launch[0] < (unsigned long long)EV_RING - 8 &&
-                      hipEventSynchronize(c->ev_ring[2 * (c->tune_launch[3] % EV_RING) + 1]) == hipSuccess;
-            for (int i = 0; i < 4 && ok; ++i)
+                      hipEventSynchronize(c->ev_ring[2 * (c->tune_launch[2 * TUNE_SAMPLES - 1] % EV_RING) + 1]) == hipSuccess;
+            for (int i = 0; i < 2 * TUNE_SAMPLES && ok; ++i)
                 ok = hipEventElapsedTime(&t[i], c->ev_ring[2 * (c->tune_launch[i] % EV_RING)], c->ev_ring[2 * (c->tune_launch[i] % EV_RING) + 1]) == hipSuccess;
             (void)hipGetLastError();
-            c->tune_choice = (ok && std::min(t[0], t[2]) < std::min(t[1], t[3])) ? 1 : 0;
+            float tm[TUNE_SAMPLES], ts[TUNE_SAMPLES];
+            for (int i = 0; i < TUNE_SAMPLES; ++i) {
+                tm[i] = t[2 * i];
+                ts[i] = t[2 * i + 1];
+            }
+            std::sort(tm, tm + TUNE_SAMPLES);
+            std::sort(ts, ts + TUNE_SAMPLES);
+            // the separate-phase loop is the default; the merged one must be faster by TUNE_MIN_GAIN in the medians to replace it
+            c->tune_choice = (ok && tm[TUNE_SAMPLES / 2] < ts[TUNE_SAMPLES / 2] * (1.0f - TUNE_MIN_GAIN)) ? 1 : 0;
             c->merged_eff = c->tune_choice;
             if (getenv("PTRT_DEBUG_LDS"))
-                fprintf(stderr, "ptrt: merged loop %.3f / %.3f ms, separate %.3f / %.3f ms -> %s\n", t[0], t[2], t[1], t[3],
+                fprintf(stderr, "ptrt: merged loop median %.3f ms, separate %.3f ms -> %s\n", tm[TUNE_SAMPLES / 2], ts[TUNE_SAMPLES / 2],
                         c->tune_choice ? "merged" : "separate");
         } else {
             c->merged_eff = c->tune_choice;
         }
     }
-    const int pmode = pair_mode(c, geom);
+    const int pmode = pair_mode(c, geom, c->merged_eff != 0);
+    c->last_pmode = pmode;
     if (c->merged < 0 && pmode == 4)
         K.steal = 0; // (the merged loop is at its best without shadow-ray subtree stealing: 3.98 vs 4.17 ms on the showcase frame)
     const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
@@ -2041,8 +2066,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     if (tuning) {
-        if (c->tune_n >= 4)
-            c->tune_launch[c->tune_n - 4] = c->launches;
+        if (c->tune_n >= TUNE_WARM)
+            c->tune_launch[c->tune_n - TUNE_WARM] = c->launches;
         ++c->tune_n;
     }
     c->launches++;
@@ -2503,17 +2528,18 @@ int ptrt_get_stats(ptrt_ctx *c, ptrt_stats *out) {
     if (int rc = set_device(c))
         return rc;
     // per-workgroup slots (no atomics in the kernel, see pt_render.hip.h): summed here
-    std::vector<unsigned long long> slots(c->n_counter_slots * 3);
+    std::vector<unsigned long long> slots(c->n_counter_slots * pt::COUNTER_WORDS);
     HIP_TRY(c, hipMemcpyAsync(slots.data(), c->d_counters, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, slots.size() * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long h[3] = {0, 0, 0};
+    unsigned long long h[pt::COUNTER_WORDS] = {0, 0, 0, 0};
     for (size_t i = 0; i < slots.size(); ++i)
-        h[i % 3] += slots[i];
+        h[i % pt::COUNTER_WORDS] += slots[i];
     out->extension_rays = h[0];
     out->shadow_rays = h[1];
     out->paths = h[2];
+    out->shadow_rays_walked = h[1] - h[3];
     return PTRT_OK;
 }
 
@@ -2577,18 +2603,44 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
     return PTRT_OK;
 }
 
+// what ptrt_set_option set, plus read-only facts about the last ptrt_render (so that a measurement can say what ran)
+int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
+    if (!ctx_live(c) || !name || !value)
+        return fail(c, PTRT_E_INVALID, "ptrt_get_option: bad argument");
+    const std::string n(name);
+    const std::pair<const char *, long long> tab[] = {
+        {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
+        {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
+        {"stage", c->stage}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
+        {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
+        // read-only: the last launch
+        {"render_mode", c->last_mode},   // 0 megakernel, 1 wavefront stages, 2 asynchronous lanes
+        {"pmode", c->last_pmode},        // PMODE of the megakernel: 0 lock-step, 1 pairs/LDS triangles, 2 queue, 3 TLAS rounds, 4 merged queue
+        {"merged_eff", c->merged_eff},   // loop shape of the last launch (1 = shadow rays ride with the next extension rays)
+        {"merged_decided", c->merged >= 0 ? 1 : (c->tune_choice >= 0 ? 1 : 0)}, // 0 while "merged" = -1 is still sampling
+        {"launches", (long long)c->launches},
+    };
+    for (const auto &e : tab)
+        if (n == e.first) {
+            *value = e.second;
+            return PTRT_OK;
+        }
+    return fail(c, PTRT_E_INVALID, "unknown option '%s'", name);
+}
+
 // test hook: which kernels rendered the last frame (0 megakernel, 1 wavefront stages)
 int ptrt_debug_last_render_mode(ptrt_ctx *c) { return ctx_live(c) ? c->last_mode : -1; }
 
-// profiling hook (not part of the drop-in surface): reads and clears pt::g_trav_stats; all zero unless
+// profiling hook (not part of the drop-in surface): reads and clears pt::g_trav_stats (32 words); all zero unless
 // the library was built with -DPT_TRAV_STATS
-int ptrt_debug_trav_stats(ptrt_ctx *c, unsigned long long *out24) {
-    if (!ctx_live(c) || !out24)
+int ptrt_debug_trav_stats(ptrt_ctx *c, unsigned long long *out32) {
+    if (!ctx_live(c) || !out32)
         return fail(c, PTRT_E_INVALID, "ptrt_debug_trav_stats: bad argument");
     if (int rc = set_device(c))
         return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpyFromSymbol(out24, HIP_SYMBOL(pt::g_trav_stats), 32 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemcpyFromSymbol(out32, HIP_SYMBOL(pt::g_trav_stats), 32 * sizeof(unsigned long long)));
     unsigned long long zero[32] = {};
     HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(pt::g_trav_stats), zero, sizeof(zero)));
     return PTRT_OK;

@@ -14,6 +14,9 @@
 // No host synchronisation inside a frame; the next render of a context waits (on its stream) until its image has
 // been taken.  RCCL is loaded on first use (dlopen), so the library has no link-time dependency on it and a
 // single-GPU box never touches it.
+// RCCL PATH UNVERIFIED ON HARDWARE: every test so far ran on a one-GPU box, where the transport is "device-copy"; dlopen,
+// ncclCommInitAll, the grouped send/receive on mixed streams (also two contexts on one remote device) and CommDestroy have
+// never executed.  tests/test_farm_gpu.py takes the devices it finds, so its first run on a multi-GPU node is that test.
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -77,6 +80,17 @@ bool farm_live(ptrt_farm *f) {
 }
 
 void farm_free(ptrt_farm *f) {
+    // nothing of the last frame may still be in flight when the communicators go: the receives and copies on the farm's
+    // stream, the sends on the contexts' streams
+    if (f->stream) {
+        (void)hipSetDevice(f->device);
+        (void)hipStreamSynchronize(f->stream);
+    }
+    for (ptrt_ctx *c : f->band)
+        if (ctx_live(c)) {
+            (void)hipSetDevice(c->device);
+            (void)hipStreamSynchronize(c->stream);
+        }
     for (size_t i = 0; i < f->comms.size(); ++i)
         if (f->comms[i]) {
             (void)hipSetDevice(f->comm_dev[i]);
@@ -284,6 +298,11 @@ int ptrt_farm_gather(ptrt_farm *f, void *out_rgb8, int out_is_device) {
     if (!out_is_device) {
         HIP_TRY(nullptr, hipMemcpyAsync(out_rgb8, frame, frame_bytes, hipMemcpyDeviceToHost, f->stream));
         HIP_TRY(nullptr, hipStreamSynchronize(f->stream));
+    } else {
+        // a presentation-ring slot as the target (rtgl::map_pbo_device_ptr -> TileFarm::render_to_device -> unmap_pbo): the
+        // slot's download must wait for the copies above, which run on the farm's NON-BLOCKING stream -- the ring's fallback
+        // (an event on the NULL stream) does not order behind it
+        ring_mark_rendered(out_rgb8, f->stream);
     }
     return PTRT_OK;
 }

@@ -44,6 +44,48 @@ inline vec3 normalize(const vec3 &v) { return v.normalized(); }
 inline vec3 lerp(const vec3 &a, const vec3 &b, float t) { return (1.0f - t) * a + t * b; }
 using point3 = vec3;
 
+// src/common/vec4.cuh:13-122 -- the homogeneous point of the motion-vector stage (denoiser_kernels.cuh:54-56).  As in the
+// reference, `/` and `/=` multiply by the rounded reciprocal (vec4.cuh:70-77, 101-103), unlike vec3's true division.
+struct vec4 {
+    float x = 0, y = 0, z = 0, w = 0;
+    vec4() = default;
+    vec4(float s) : x(s), y(s), z(s), w(s) {}
+    vec4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    vec4(const vec3 &v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+    vec3 xyz() const { return vec3(x, y, z); }
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : (i == 2 ? z : w)); }
+    float &operator[](int i) { return i == 0 ? x : (i == 1 ? y : (i == 2 ? z : w)); }
+    vec4 operator-() const { return vec4(-x, -y, -z, -w); }
+    vec4 &operator+=(const vec4 &v) { x += v.x; y += v.y; z += v.z; w += v.w; return *this; }
+    vec4 &operator-=(const vec4 &v) { x -= v.x; y -= v.y; z -= v.z; w -= v.w; return *this; }
+    vec4 &operator*=(float s) { x *= s; y *= s; z *= s; w *= s; return *this; }
+    vec4 &operator/=(float s) { const float inv = 1.0f / s; x *= inv; y *= inv; z *= inv; w *= inv; return *this; }
+};
+inline vec4 operator+(const vec4 &a, const vec4 &b) { return vec4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+inline vec4 operator-(const vec4 &a, const vec4 &b) { return vec4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+inline vec4 operator*(const vec4 &v, float s) { return vec4(v.x * s, v.y * s, v.z * s, v.w * s); }
+inline vec4 operator*(float s, const vec4 &v) { return v * s; }
+inline vec4 operator/(const vec4 &v, float s) { return v * (1.0f / s); }
+inline float dot(const vec4 &a, const vec4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+inline float length(const vec4 &v) { return std::sqrt(dot(v, v)); }
+inline vec4 normalize(const vec4 &v) { return v / length(v); }
+inline float length(const vec3 &v) { return v.length(); } // vec3.cuh free function, used by Triangle::area
+
+// src/common/ray.cuh:9-34
+class Ray {
+  public:
+    point3 orig;
+    vec3 dir;
+    bool spec = false;
+    Ray() {}
+    Ray(const point3 &origin, const vec3 &direction) : orig(origin), dir(direction), spec(false) {}
+    Ray(const point3 &origin, const vec3 &direction, bool is_specular) : orig(origin), dir(direction), spec(is_specular) {}
+    point3 origin() const { return orig; }
+    vec3 direction() const { return dir; }
+    bool isSpecular() const { return spec; }
+    point3 at(float t) const { return orig + t * dir; }
+};
+
 #ifndef PI
 #define PI 3.14159265358979323846f
 #endif

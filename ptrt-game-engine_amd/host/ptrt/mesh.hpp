@@ -16,10 +16,47 @@
 #include <string>
 #include <vector>
 
-struct Triangle { // src/common/triangle.cuh:15-28 (the fields addTriangles reads)
+// src/common/triangle.cuh:15-92 -- the input type of Scene::addTriangles (which reads v0, v1, v2).  The other public
+// members are kept for callers that use them: pre-computed edges, the unnormalised normal, and the two-sided
+// Moeller-Trumbore test of the OLD intersection code (host arithmetic; the render path has its own, intersection.cuh:219).
+struct Triangle {
     vec3 v0, v1, v2;
+    vec3 e1, e2; // v1 - v0, v2 - v0
+    vec3 n;      // cross(e1, e2), not unit length
     Triangle() = default;
-    Triangle(const vec3 &a, const vec3 &b, const vec3 &c) : v0(a), v1(b), v2(c) {}
+    Triangle(const vec3 &a, const vec3 &b, const vec3 &c) : v0(a), v1(b), v2(c) {
+        e1 = v1 - v0;
+        e2 = v2 - v0;
+        n = cross(e1, e2);
+    }
+    vec3 normal() const { return normalize(n); }
+    float area() const { return 0.5f * length(n); }
+    void bounds(vec3 &bmin, vec3 &bmax) const {
+        bmin.x = fminf(v0.x, fminf(v1.x, v2.x));
+        bmin.y = fminf(v0.y, fminf(v1.y, v2.y));
+        bmin.z = fminf(v0.z, fminf(v1.z, v2.z));
+        bmax.x = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+        bmax.y = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+        bmax.z = fmaxf(v0.z, fmaxf(v1.z, v2.z));
+    }
+    bool intersect(const Ray &ray, float &t, float &u, float &v) const { // two-sided (RT_CULL_BACKFACES 0, the default)
+        const float EPS = 1e-6f;
+        const vec3 pvec = cross(ray.direction(), e2);
+        const float det = dot(e1, pvec);
+        if (fabsf(det) < EPS)
+            return false;
+        const float invDet = 1.0f / det;
+        const vec3 tvec = ray.origin() - v0;
+        u = dot(tvec, pvec) * invDet;
+        if (u < 0.0f || u > 1.0f)
+            return false;
+        const vec3 qvec = cross(tvec, e1);
+        v = dot(ray.direction(), qvec) * invDet;
+        if (v < 0.0f || (u + v) > 1.0f)
+            return false;
+        t = dot(e2, qvec) * invDet;
+        return t > EPS;
+    }
 };
 
 using Tri = ptrt_tri;                // mesh.cuh:45-47
@@ -121,15 +158,50 @@ class Mesh {
                 while (p < eol && (*p == ' ' || *p == '\t' || *p == '\r'))
                     ++p;
             }
+            // a decimal real as `istream >> float` takes it: [sign] digits [. digits] [e|E [sign] digits] -- the token is
+            // delimited HERE, so strtof never sees the "nan", "inf" / "infinity" or hexadecimal forms it would accept and
+            // the stream extraction of the reference refuses ("0x1p3" reads as 0 and the record then fails at the 'x');
+            // an overflowing value fails like the extraction's failbit does
             bool real(float &out) {
                 blanks();
-                if (p >= eol)
+                const char *q = p;
+                if (q < eol && (*q == '-' || *q == '+'))
+                    ++q;
+                const char *d0 = q;
+                while (q < eol && *q >= '0' && *q <= '9')
+                    ++q;
+                int mant = (int)(q - d0);
+                if (q < eol && *q == '.') {
+                    const char *f0 = ++q;
+                    while (q < eol && *q >= '0' && *q <= '9')
+                        ++q;
+                    mant += (int)(q - f0);
+                }
+                if (mant == 0)
                     return false;
-                char *stop = nullptr;
-                const float v = std::strtof(p, &stop); // (the record's line ends in '\n' or the buffer's NUL)
-                if (stop == p || stop > eol)
+                if (q < eol && (*q == 'e' || *q == 'E')) {
+                    const char *e = q + 1;
+                    if (e < eol && (*e == '-' || *e == '+'))
+                        ++e;
+                    if (e < eol && *e >= '0' && *e <= '9') {
+                        while (e < eol && *e >= '0' && *e <= '9')
+                            ++e;
+                        q = e;
+                    }
+                }
+                char buf[64];
+                const size_t n = (size_t)(q - p);
+                float v;
+                if (n < sizeof buf) {
+                    std::memcpy(buf, p, n);
+                    buf[n] = 0;
+                    v = std::strtof(buf, nullptr);
+                } else {
+                    v = std::strtof(std::string(p, n).c_str(), nullptr);
+                }
+                if (!(v - v == 0.0f)) // overflow to infinity
                     return false;
-                p = stop;
+                p = q;
                 out = v;
                 return true;
             }
@@ -141,10 +213,17 @@ class Mesh {
                     neg = *q++ == '-';
                 if (q >= eol || *q < '0' || *q > '9')
                     return false;
-                long v = 0;
-                while (q < eol && *q >= '0' && *q <= '9')
+                long long v = 0;
+                bool over = false;
+                while (q < eol && *q >= '0' && *q <= '9') {
                     v = v * 10 + (*q++ - '0');
+                    over = over || v > 2147483648ll; // (from here on the value no longer matters: no overflow of v itself)
+                    if (over)
+                        v = 0;
+                }
                 p = q;
+                if (over || (neg ? -v : v) > 2147483647ll)
+                    return false; // `istream >> int` sets failbit on a value outside int: the face record ends here
                 out = (int)(neg ? -v : v);
                 return true;
             }

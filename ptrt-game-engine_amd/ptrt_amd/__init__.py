@@ -25,6 +25,16 @@ if not os.path.exists(LIB_PATH):
     )
 lib = C.CDLL(LIB_PATH)
 
+
+def library_info():
+    """Path and SHA-256 (first 16 hex digits) of the shared library this process loaded -- PTRT_AMD_LIB can swap it, so a
+    measurement names it."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return {"path": os.path.relpath(LIB_PATH, os.path.dirname(os.path.dirname(_HERE))), "sha16": hashlib.sha256(f.read()).hexdigest()[:16],
+                "from_env": bool(os.environ.get("PTRT_AMD_LIB"))}
+
+
 PTRT_OK = 0
 BUF_ACCUM, BUF_NORMAL, BUF_DEPTH, BUF_OBJECT_ID, BUF_RGB8, BUF_RNG, BUF_DENOISED, BUF_MOTION, BUF_RENDER_ACCUM = range(9)
 DEFAULT_SEED = 12345
@@ -93,7 +103,8 @@ class Hit(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64)]
+    _fields_ = [("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
+                ("shadow_rays_walked", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3),
@@ -134,6 +145,7 @@ _sig("ptrt_write_rng", C.c_int, _vp, C.POINTER(C.c_uint32), C.c_size_t)
 _sig("ptrt_trace_rays", C.c_int, _vp, _fp, _fp, C.c_int, _vp)
 _sig("ptrt_get_stats", C.c_int, _vp, C.POINTER(Stats))
 _sig("ptrt_set_option", C.c_int, _vp, C.c_char_p, C.c_longlong)
+_sig("ptrt_get_option", C.c_int, _vp, C.c_char_p, C.POINTER(C.c_longlong))
 _sig("ptrt_last_kernel_ms", C.c_int, _vp, _fp, _fp)
 _sig("ptrt_set_stream", C.c_int, _vp, _vp)
 _sig("ptrt_kernel_ms_history", C.c_int, _vp, _fp, C.c_int)
@@ -544,10 +556,16 @@ class Scene:
     def reset_rng(self, seed=DEFAULT_SEED): self._cchk(lib.ptrt_reset_rng(self.ctx, seed))
     def set_option(self, name, value): self._cchk(lib.ptrt_set_option(self.ctx, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = C.c_longlong(0)
+        self._cchk(lib.ptrt_get_option(self.ctx, name.encode(), C.byref(v)))
+        return v.value
+
     def stats(self):
         s = Stats()
         self._cchk(lib.ptrt_get_stats(self.ctx, C.byref(s)))
-        return dict(extension_rays=s.extension_rays, shadow_rays=s.shadow_rays, paths=s.paths)
+        return dict(extension_rays=s.extension_rays, shadow_rays=s.shadow_rays, paths=s.paths,
+                    shadow_rays_walked=s.shadow_rays_walked)
 
     def last_kernel_ms(self):
         a = C.c_float()

@@ -22,7 +22,7 @@ def run_probe():
     doc["blue_noise"]["sha256"] = hashlib.sha256(bn.tobytes()).hexdigest()
     doc["blue_noise"]["first64_bits"] = [int(v) for v in bn[:64]]
     doc["built_from"] = ("common/bluenoise.cuh, pathtracer/rendering/taa.cuh, pathtracer/scene/lights.cuh, "
-                         "common/vec3.cuh, common/ray.cuh, common/matrix.cuh of the reference; g++ -O2 -ffp-contract=off, libstdc++")
+                         "common/vec3.cuh, common/ray.cuh, common/matrix.cuh, common/vec4.cuh, common/triangle.cuh of the reference; g++ -O2 -ffp-contract=off, libstdc++")
     return doc
 
 

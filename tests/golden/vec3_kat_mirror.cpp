@@ -1,7 +1,9 @@
-// Test helper (built by tests/test_ref_probe.py with g++): the vec3 known-answer rows of oracle/ref_probe.cpp
-// evaluated with the host mirror's vec3 (ptrt-game-engine_amd/host/ptrt/math.hpp) -- same seeded inputs, same
+// Test helper (built by tests/test_ref_probe.py with g++): the vec3, vec4 and Triangle known-answer rows of oracle/ref_probe.cpp
+// evaluated with the host mirror's types (ptrt-game-engine_amd/host/ptrt/{math,mesh}.hpp) -- same seeded inputs, same
 // expressions, results as bit patterns, one row per line.
-#include "ptrt/math.hpp"
+#include "ptrt/mesh.hpp"
+
+#include <cstddef>
 
 #include <cstdint>
 #include <cstdio>
@@ -27,6 +29,44 @@ int main() {
         printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u\n", bits(dot(a, b)), bits(a.length()),
                bits(a.length_squared()), bits(c.x), bits(c.y), bits(c.z), bits(n.x), bits(n.y), bits(n.z), bits(r.x), bits(r.y),
                bits(r.z), bits(l.x), bits(l.y), bits(l.z), bits(q.x), bits(q.y), bits(q.z));
+    }
+    // second block (after a line holding "--"): layout, vec4 and (third block) Triangle known answers of the same probe
+    printf("--\n%zu %zu %zu %zu %zu %zu %zu\n", sizeof(vec4), offsetof(vec4, w), sizeof(Triangle), offsetof(Triangle, v1),
+           offsetof(Triangle, e1), offsetof(Triangle, e2), offsetof(Triangle, n));
+    // (the generator goes on where the probe's does: its mat3 block draws 24 * (9 + 9 + 3) values in between)
+    for (int k = 0; k < 24 * 21; ++k)
+        rnd();
+    for (int k = 0; k < 24; ++k) {
+        const float ax = rnd(), ay = rnd(), az = rnd(), aw = rnd(), bx = rnd(), by = rnd(), bz = rnd(), bw = rnd(), t = rnd();
+        const vec4 a(ax, ay, az, aw), b(vec3(bx, by, bz), bw);
+        vec4 c = a;
+        c += b;
+        c *= t;
+        c -= a;
+        c /= bw;
+        const vec4 q = (a + b) * t - b / aw + t * (-a), nn = normalize(b);
+        const vec3 xyz = b.xyz();
+        printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u\n", bits(dot(a, b)), bits(length(a)), bits(c.x), bits(c.y),
+               bits(c.z), bits(c.w), bits(q.x), bits(q.y), bits(q.z), bits(q.w), bits(nn.x), bits(nn.y), bits(nn.z), bits(nn.w), bits(xyz.x),
+               bits(xyz.y), bits(xyz.z), bits(b[3]), bits(vec4(t)[2]));
+    }
+    printf("--\n");
+    for (int k = 0; k < 32; ++k) {
+        float f[14];
+        for (float &x : f) x = rnd();
+        const vec3 v0(f[0], f[1], f[2]), v1(f[3], f[4], f[5]), v2(f[6], f[7], f[8]), o(f[9], f[10], f[11] + 9.0f);
+        const float wu = f[12] * 0.16f + 0.3f, wv = f[13] * 0.16f + 0.3f;
+        const Triangle T(v0, v1, v2);
+        const vec3 target = v0 + wu * T.e1 + wv * T.e2, d = normalize(target - o);
+        vec3 bmin, bmax;
+        T.bounds(bmin, bmax);
+        float t = 0.0f, u = 0.0f, v = 0.0f;
+        const bool hit = T.intersect(Ray(o, d), t, u, v);
+        const vec3 nrm = T.normal();
+        printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %d %u %u %u\n", bits(T.e1.x), bits(T.e1.y), bits(T.e1.z),
+               bits(T.e2.x), bits(T.e2.y), bits(T.e2.z), bits(T.n.x), bits(T.n.y), bits(T.n.z), bits(nrm.x), bits(nrm.y), bits(nrm.z),
+               bits(T.area()), bits(bmin.x), bits(bmin.y), bits(bmin.z), bits(bmax.x), bits(bmax.y), bits(bmax.z), hit ? 1 : 0,
+               hit ? bits(t) : 0u, hit ? bits(u) : 0u, hit ? bits(v) : 0u);
     }
     return 0;
 }

@@ -23,7 +23,7 @@ def test_cornell_single_leaf_blases(P, O, blue_noise, size, spp, depth, frames):
     s.set_option("async_lanes", 1)
     gpu, cpu = render_both(P, O, s, blue_noise, spp, depth, frames)
     assert mode(P, s) == 2
-    assert_frames_equal(gpu, cpu)
+    assert_frames_equal(gpu, cpu, walks_all=True)
     s.close()
 
 
@@ -35,7 +35,7 @@ def test_showcase_all_material_branches(P, O, blue_noise, shade_min):
     s.set_option("shade_min", shade_min)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 5, 2)
     assert mode(P, s) == 2
-    assert_frames_equal(gpu, cpu)
+    assert_frames_equal(gpu, cpu, walks_all=True)
     s.close()
 
 
@@ -54,7 +54,7 @@ def test_instanced_meshes_and_thin_lens(P, O, blue_noise):
     s.set_option("async_lanes", 1)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
     if mode(P, s) == 2:  # a small leaf target can make the TLAS a real tree, which the stages do not take
-        assert_frames_equal(gpu, cpu)
+        assert_frames_equal(gpu, cpu, walks_all=True)
     s.close()
     s = P.Scene(64, 48)
     P.scenes.cornell(s)
@@ -62,7 +62,7 @@ def test_instanced_meshes_and_thin_lens(P, O, blue_noise):
     s.set_option("async_lanes", 1)
     gpu, cpu = render_both(P, O, s, blue_noise, 3, 4, 2)
     assert mode(P, s) == 2
-    assert_frames_equal(gpu, cpu)
+    assert_frames_equal(gpu, cpu, walks_all=True)
     s.close()
 
 
@@ -72,7 +72,7 @@ def test_band_context(P, O, blue_noise):
     s.set_option("async_lanes", 1)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 1)
     assert mode(P, s) == 2
-    assert_frames_equal(gpu, cpu)
+    assert_frames_equal(gpu, cpu, walks_all=True)
     s.close()
 
 
@@ -101,4 +101,7 @@ def test_equals_megakernel_at_scale(P, blue_noise):
     for a, b in zip(*out):
         for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):
             assert np.array_equal(bits(a[k]), bits(b[k])), k
-        assert a["stats"] == b["stats"]
+        # (the megakernel counts the zero-valued light samples but does not walk them; this shape walks every shadow ray)
+        assert b["stats"]["shadow_rays_walked"] == b["stats"]["shadow_rays"] >= a["stats"]["shadow_rays_walked"]
+        strip = lambda d: {k: v for k, v in d.items() if k != "shadow_rays_walked"}
+        assert strip(a["stats"]) == strip(b["stats"])

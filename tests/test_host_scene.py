@@ -185,6 +185,16 @@ def test_obj_loader(P, tmp_path):
     v2, f2, *_ = np_mesh(s.flatten(), m2)
     assert v2.shape == (4, 3) and np.allclose(v2.mean(0), 0, atol=1e-7) and np.allclose(v2[0], (-1, -1, 0))
     assert f2.tolist() == [[0, 1, 2], [0, 2, 3], [3, 0, 1], [3, 2, 1], [3, 1, 0]]
+    # what `istream >> float / int` refuses is refused: nan, inf, hexadecimal and overflowing reals drop their `v` record
+    # (the later vertices keep their numbers), an index outside int ends its `f` record; ".5", "5.", "+1", "1E+0" are reals
+    obj3 = tmp_path / "odd.obj"
+    obj3.write_text("v nan 0 0\nv 0 inf 0\nv 0x10 0 0\nv 1e99 0 0\nv infinity 1 1\nv .5 5. +1\nv 1E+0 -2e-1 3.25e0\nv 0 0 0\nv 1 1 1\n"
+                    "f 1 2 3 99999999999 4\nf 1 2 99999999999999999999999 3 4\nf 4 3 2\n")
+    m3 = s.addMesh(str(obj3), P.Material((1, 1, 1)))
+    v3, f3, *_ = np_mesh(s.flatten(), m3)
+    assert v3.shape == (4, 3)
+    assert np.allclose(v3 + np.array([0.625, 1.45, 1.3125], np.float32), [(.5, 5, 1), (1, -.2, 3.25), (0, 0, 0), (1, 1, 1)], atol=1e-6)
+    assert f3.tolist() == [[0, 1, 2], [3, 2, 1]]
     empty = tmp_path / "empty.obj"
     empty.write_text("# nothing\nvn 0 0 1\n")
     with pytest.raises(P.PtrtError, match="no valid geometry"):

@@ -22,7 +22,7 @@ def test_depth1_is_black_one_ray_per_pixel(P, O, blue_noise):
     rng = O.xorwow_init(12345, 0, 64 * 64)
     r = O.render(s.flatten(), 64, 64, 1, 1, 0, blue_noise, rng, threads=4)
     assert not r["accum"].any()
-    assert r["stats"] == dict(extension_rays=4096, shadow_rays=0, paths=4096)
+    assert r["stats"] == dict(extension_rays=4096, shadow_rays=0, paths=4096, shadow_rays_walked=0)
     assert (r["object_id"] >= 0).all() and set(np.unique(r["object_id"])) <= set(range(8))
     assert np.all(r["depth"] > 4.9) and np.all(r["depth"] < 17)
     assert np.allclose(np.linalg.norm(r["normal"], axis=1), 1.0, atol=1e-6)

@@ -65,6 +65,21 @@ def build_scene(P, name, W, H, y0, rows, device, interleave=None):
     return s
 
 
+def cpu_quota():
+    """CPU time this process's cgroup may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(P, scene_name, W, H, spp, depth, frame, threads):
     """The oracle ("port" of the reference path; the reference has no CPU renderer) timed on this box's host cores
     over a bounded sample of the same frame: all-core on a band of rows, and one core on a narrower band."""
@@ -96,7 +111,10 @@ def cpu_baseline(P, scene_name, W, H, spp, depth, frame, threads):
     if allc > threads:
         raysA, dtA, y0A = sample(rows, allc)
         all_core = {"value": round(raysA / dtA / 1e6, 3), "unit": "Mrays/s", "cores": allc,
-                    "sample": f"rows {y0A}..{y0A + rows}, {raysA} rays in {dtA:.2f} s"}
+                    "sample": f"rows {y0A}..{y0A + rows}, {raysA} rays in {dtA:.2f} s",
+                    # (a container's CPU quota caps what `cores` threads can use: when it is below them this is the
+                    # quota's worth of cores, not the machine's)
+                    "cgroup_cpu_quota_cores": cpu_quota()}
     s.close()
     out = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
            "host_cores": os.cpu_count(),
@@ -184,19 +202,34 @@ class Farm:
                 self.out_frame = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
         # config 5 ("fluid"): every step first moves the water surface (new vertex positions already in
         # HBM), refits the BVH on the GPU, then traces: the refit+trace pipeline, no host sync inside
-        self.water = None
+        # --fluid-source: where the new positions come from.  "device": already in HBM (a simulation on the GPU);
+        # "host": pinned host memory, so every step also crosses PCIe (4.7 MB, SURVEY's "upload verts -> refit -> trace");
+        # "commit": the reference's own caller -- what updatePTScene does to a `Triangles` mesh (vertices and faces rewritten on
+        # the host, dirty flags set) followed by the unchanged commitObjectChanges(), under the GpuRefit policy
+        self.water = self.water_host = None
+        self.fluid_source = (args.fluid_source if args else "device")
         if scene_name == "fluid":
             import numpy as np
-            self.water = [torch.from_numpy(np.ascontiguousarray(P.scenes.water_vertices(256, t / 60.0))).cuda()
-                          for t in range(8)]
+            host = [np.ascontiguousarray(P.scenes.water_vertices(256, t / 60.0)) for t in range(8)]
+            self.water = [torch.from_numpy(a).cuda() for a in host]
+            self.water_host = [torch.from_numpy(a).pin_memory() for a in host]
+            self.water_np = host
+            s.setDynamicGeometryPolicy("GpuRebuild" if self.rebuild else "GpuRefit")  # (only "commit" goes through it)
         self.counter = [0, 0]
 
     def step(self):
         s, env, tf = self.scene, self.env, self.tilefarm
         rank, world, rehearse = env["rank"], env["world"], env["rehearse"]
         if self.water is not None:
-            move = s.rebuildFromDevice if self.rebuild else s.refitFromDevice
-            move(s.water_mesh, self.water[self.counter[0] % len(self.water)].data_ptr())
+            i = self.counter[0] % len(self.water)
+            if self.fluid_source == "commit":
+                s.setTriangleSoup(s.water_mesh, self.water_np[i])
+                s.commitObjectChanges()
+            elif self.fluid_source == "host" and not self.rebuild:
+                s.refitFromHost(s.water_mesh, self.water_host[i].data_ptr())
+            else:
+                move = s.rebuildFromDevice if self.rebuild else s.refitFromDevice
+                move(s.water_mesh, self.water[i].data_ptr())
             self.counter[0] += 1
         b = self.counter[1] & 1
         self.counter[1] += 1
@@ -345,14 +378,21 @@ def main():
     ap.add_argument("--farm", type=int, default=0, metavar="PARTS",
                     help="N=1 only, not the headline: also time the single-process C++ TileFarm (ptrt_farm_*) with PARTS "
                          "parts over the visible devices and report config.farm_ms_per_frame")
+    ap.add_argument("--fluid-source", default="device", choices=["device", "host", "commit"],
+                    help="fluid scene: new vertex positions from HBM (default), from pinned host memory (H2D inside the step), or "
+                         "through the reference's caller: updatePTScene's vertex rewrite + commitObjectChanges()")
+    ap.add_argument("--via-commit", action="store_true", help="= --fluid-source commit")
     ap.add_argument("--rebuild", action="store_true",
                     help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
     args = ap.parse_args()
+    if args.via_commit:
+        args.fluid_source = "commit"
     cfg = dict(CONFIGS[args.config])
     for k in ("scene", "width", "height", "spp", "depth"):
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
-    plain = not (args.denoise or args.bloom or args.preset or args.opt or args.scale != 1.0 or args.rebuild)
+    plain = not (args.denoise or args.bloom or args.preset or args.opt or args.scale != 1.0 or args.rebuild or
+                 args.fluid_source != "device")
     headline = cfg == CONFIGS["cornell1080"] and plain
     # the committed profile (instruction counts, lane occupancy, HBM traffic) that belongs to this very workload, if any
     profile_key = None
@@ -390,6 +430,22 @@ def main():
     farm = Farm(P, torch, dist, tilefarm, env, cfg["scene"], W, H, cfg["spp"], cfg["depth"], args=args, preset=args.preset)
     m = farm.measure(args.steps, args.warmup)
     settings = farm.scene.settings()
+    fluid_sources = None
+    if cfg["scene"] == "fluid" and world == 1 and not args.rebuild:
+        # configs[4] three ways (the line's value is --fluid-source, default "device"): ms per frame of the same pipeline with
+        # the positions already in HBM, crossing PCIe from pinned memory, and through the reference's caller + commit
+        fluid_sources = {args.fluid_source + "_ms": round(m["dt"] / args.steps * 1e3, 4)}
+        for src in ("device", "host", "commit"):
+            if src != args.fluid_source:
+                farm.fluid_source = src
+                ms = farm.measure(max(4, args.steps // 2), 3)
+                fluid_sources[src + "_ms"] = round(ms["dt"] / ms["steps"] * 1e3, 4)
+        farm.fluid_source = args.fluid_source
+        fluid_sources["gpu_commits, geometry_uploads"] = list(farm.scene.commitCounts())
+        fluid_sources["note"] = ("device: positions resident in HBM; host: + 4.7 MB H2D from pinned memory per step; commit: the "
+                                 "reference's caller (updatePTScene's rewrite of mesh->vertices/faces on the host, dirty flags, "
+                                 "commitObjectChanges()) under Scene::setDynamicGeometryPolicy(GpuRefit) -- its host work "
+                                 "(393,216 push_backs, the local box, pageable H2D) is the reference's, not the back end's")
     present = None
     if args.present > 0 and world == 1:
         farm.scene.set_stream(0)  # the viewer loop runs on the context's own stream
@@ -470,6 +526,9 @@ def main():
     }
     if c3 is not None:
         out["configs3"] = c3
+    if fluid_sources is not None:
+        out["config"]["fluid_sources"] = fluid_sources
+        out["config"]["fluid_source"] = args.fluid_source
     if farm_ms is not None:
         out["config"]["farm_ms_per_frame"] = round(farm_ms, 4)
         out["config"]["farm"] = f"{args.farm} parts, {args.layout}, one process, transport {farm_transport}"

@@ -174,6 +174,7 @@ struct ptrt_ctx {
     int tune_n = 0, tune_choice = -1;    // auto: frames measured so far (variants alternate), the decision (-1: none yet)
     unsigned long long tune_key = ~0ull, tune_launch[2 * TUNE_SAMPLES] = {};
     int last_pmode = 0;                  // PMODE of the last megakernel launch (ptrt_get_option "pmode")
+    bool last_merged_possible = false;   // ... and whether that scene has the two loop shapes to choose from
     bool timed = false;
 };
 
@@ -1945,6 +1946,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // ring) decide the rest at frame 8, which waits for frame 7 once
     bool tuning = false;
     const bool merged_possible = pair_mode(c, geom, true) == 4; // (only the queue mode over BLASes has the merged shape)
+    c->last_merged_possible = merged_possible;
     c->merged_eff = c->merged > 0 ? 1 : 0;
     bool capturing = false; // (a caller recording this stream into a hipGraph: no host wait, no choice -- the default shape)
     {
@@ -2618,7 +2620,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
         {"render_mode", c->last_mode},   // 0 megakernel, 1 wavefront stages, 2 asynchronous lanes
         {"pmode", c->last_pmode},        // PMODE of the megakernel: 0 lock-step, 1 pairs/LDS triangles, 2 queue, 3 TLAS rounds, 4 merged queue
         {"merged_eff", c->merged_eff},   // loop shape of the last launch (1 = shadow rays ride with the next extension rays)
-        {"merged_decided", c->merged >= 0 ? 1 : (c->tune_choice >= 0 ? 1 : 0)}, // 0 while "merged" = -1 is still sampling
+        {"merged_decided", (c->merged >= 0 || c->tune_choice >= 0 || !c->last_merged_possible) ? 1 : 0}, // 0 while "merged" = -1 is still sampling
         {"launches", (long long)c->launches},
     };
     for (const auto &e : tab)

@@ -170,6 +170,45 @@ int hs_mesh_set_vertices(void *s, int mesh, const float *xyz, int n_verts) {
     m->vertsDirty = true;
     return 0;
 }
+// What updatePTScene does to a `Triangles` mesh whose triangleVerts changed (PTRTtransfer.cuh:2249-2270): vertices and faces
+// rewritten as an unshared-vertex soup, both dirty flags set, the local box recomputed -- the caller commits afterwards.
+int hs_mesh_set_triangle_soup(void *s, int mesh, const float *verts9, int n_tris) {
+    Mesh *m = static_cast<Scene *>(s)->getMesh((size_t)mesh);
+    if (!m || !verts9 || n_tris < 1) {
+        g_err = "hs_mesh_set_triangle_soup: bad argument";
+        return -1;
+    }
+    m->vertices.clear();
+    m->faces.clear();
+    m->vertices.reserve((size_t)n_tris * 3);
+    m->faces.reserve((size_t)n_tris);
+    for (int i = 0; i < n_tris; ++i) {
+        const int base = (int)m->vertices.size();
+        for (int k = 0; k < 3; ++k)
+            m->vertices.push_back(vec3(verts9[i * 9 + k * 3], verts9[i * 9 + k * 3 + 1], verts9[i * 9 + k * 3 + 2]));
+        m->faces.push_back(Tri{base, base + 1, base + 2});
+    }
+    m->bvhDirty = true;
+    m->vertsDirty = true;
+    m->computeLocalAABB();
+    return 0;
+}
+int hs_set_dynamic_geometry_policy(void *s, int policy) {
+    if (policy < 0 || policy > 2) {
+        g_err = "policy must be 0 (HostRebuild), 1 (GpuRefit) or 2 (GpuRebuild)";
+        return -1;
+    }
+    static_cast<Scene *>(s)->setDynamicGeometryPolicy((Scene::DynamicGeometryPolicy)policy);
+    return 0;
+}
+int hs_commit_counts(void *s, long long *gpu_commits, long long *geometry_uploads) {
+    const Scene *sc = static_cast<Scene *>(s);
+    if (gpu_commits)
+        *gpu_commits = (long long)sc->gpuDynamicCommitCount();
+    if (geometry_uploads)
+        *geometry_uploads = (long long)sc->geometryUploadCount();
+    return 0;
+}
 int hs_mesh_counts(void *s, int mesh, int *n_verts, int *n_faces, int *n_nodes) {
     Mesh *m = static_cast<Scene *>(s)->getMesh((size_t)mesh);
     if (!m)
@@ -256,6 +295,10 @@ int hs_commit_object_changes(void *s) { HS_TRY(static_cast<Scene *>(s)->commitOb
 int hs_refit_object_changes(void *s) { HS_TRY(static_cast<Scene *>(s)->refitObjectChanges()); return 0; }
 int hs_refit_from_device(void *s, int mesh, const void *device_xyz) {
     HS_TRY(static_cast<Scene *>(s)->refitFromDevice((size_t)mesh, static_cast<const float *>(device_xyz)));
+    return 0;
+}
+int hs_refit_from_host(void *s, int mesh, const float *host_xyz) {
+    HS_TRY(static_cast<Scene *>(s)->refitFromHost((size_t)mesh, host_xyz));
     return 0;
 }
 int hs_rebuild_object_changes(void *s, int sync_host_copy) {

@@ -518,6 +518,31 @@ class Scene {
     void scaleMesh(size_t i, float s) { if (Mesh *m = getMesh(i)) m->scale(s); }
     void scaleMesh(size_t i, const vec3 &s) { if (Mesh *m = getMesh(i)) m->scale(s); }
     void commitObjectChanges() { updateAccelerationStructures(); resetAccumulation(); } // scene.cuh:1784
+    // What commitObjectChanges() / render_to_device() do with a mesh whose vertices were rewritten (bvhDirty / vertsDirty set
+    // by the caller, as updatePTScene does for a `Triangles` mesh, PTRTtransfer.cuh:2249-2270, or by the vertex-baking
+    // transforms) while its vertex count and face list are what was uploaded:
+    //   HostRebuild (default) -- the reference: Mesh::buildBVH on the CPU, every mesh re-laid-out and re-uploaded
+    //                            (scene.cuh:656-733);
+    //   GpuRefit   -- the uploaded tree is kept: the new positions go to the device (ptrt_update_vertices) and the boxes are
+    //                 refitted there (ptrt_refit); no host build, no re-upload of the arena;
+    //   GpuRebuild -- as GpuRefit, but the faces are re-assigned to the leaves in Morton order first (ptrt_build_bvh).
+    // A changed face list, vertex count, a new mesh, or a mesh without an uploaded tree falls back to HostRebuild for that
+    // commit.  The host copy of a tree kept on the GPU is brought up to date when something reads it (flatten(), a real
+    // TLAS, the next full upload).  So the UNCHANGED call sequence updatePTScene(scene, unified) -> commitObjectChanges()
+    // reaches the GPU refit once the application has said  scene.setDynamicGeometryPolicy(...)  after building it.
+    enum class DynamicGeometryPolicy { HostRebuild = 0, GpuRefit = 1, GpuRebuild = 2 };
+    void setDynamicGeometryPolicy(DynamicGeometryPolicy p) {
+        // (chosen after the upload: the face lists of the meshes nobody has touched since are what the device holds)
+        if (p != DynamicGeometryPolicy::HostRebuild && gpu_resources_initialized && !geometryDirty && uploadedFaces.size() == meshes.size())
+            for (size_t i = 0; i < meshes.size(); ++i)
+                if (uploadedFaces[i].empty() && !meshes[i]->bvhDirty && !meshes[i]->vertsDirty)
+                    uploadedFaces[i] = meshes[i]->faces;
+        dynPolicy = p;
+    }
+    DynamicGeometryPolicy getDynamicGeometryPolicy() const { return dynPolicy; }
+    // commits that took the GPU path / that re-uploaded the geometry (tests, bench)
+    size_t gpuDynamicCommitCount() const { return gpuDynamicCommits; }
+    size_t geometryUploadCount() const { return geometryUploads; }
     // Dynamic geometry with unchanged topology (the fluid-sim caller, PTRTtransfer.cuh:2249-2270):
     // instead of commitObjectChanges()' full CPU rebuild, keep every tree and refit its boxes --
     // on the host copy (so flatten() stays consistent) and on the GPU (ptrt_update_vertices +
@@ -564,6 +589,20 @@ class Scene {
             throw std::runtime_error("refitFromDevice: a TLAS with inner nodes is rebuilt on the host, which needs the "
                                      "vertices (use setVertices + refitObjectChanges)");
         check(ptrt_update_vertices(ctx, (int)mesh, device_xyz, (int)m->vertices.size(), 1), "Failed to update vertices");
+        check(ptrt_refit(ctx), "Failed to refit");
+        resetAccumulation();
+    }
+
+    // same from HOST memory without touching the host copy of the mesh (its vertices are whatever the caller last put
+    // there; the host tree is refitted when something reads it): ptrt_update_vertices(on_device = 0) + ptrt_refit
+    void refitFromHost(size_t mesh, const float *host_xyz) {
+        needBackend();
+        Mesh *m = getMesh(mesh);
+        if (!m)
+            throw std::runtime_error("refitFromHost: no such mesh");
+        if (h_tlasNodes.size() > 1)
+            throw std::runtime_error("refitFromHost: a TLAS with inner nodes is rebuilt on the host (use setVertices + refitObjectChanges)");
+        check(ptrt_update_vertices(ctx, (int)mesh, host_xyz, (int)m->vertices.size(), 0), "Failed to update vertices");
         check(ptrt_refit(ctx), "Failed to refit");
         resetAccumulation();
     }
@@ -741,6 +780,7 @@ class Scene {
         }
         if (meshes.size() != mesh_materials.size())
             throw std::runtime_error("Mesh count and material count mismatch!");
+        needBackend();
         updateAccelerationStructures();
         gpu_resources_initialized = true;
         resetAccumulation();
@@ -908,6 +948,12 @@ class Scene {
             clearcoatRoughness, subsurfaceRadius, anisotropy, sheen, iridescence, iridescenceThickness;
     } soa;
     ptrt_scene_desc flat{};
+    // dynamic-geometry policy: the face lists and vertex counts of the last upload, and which host trees lag the device's
+    DynamicGeometryPolicy dynPolicy = DynamicGeometryPolicy::HostRebuild;
+    std::vector<std::vector<Tri>> uploadedFaces;
+    std::vector<size_t> uploadedVerts;
+    std::vector<unsigned char> hostTreeStale;
+    size_t gpuDynamicCommits = 0, geometryUploads = 0;
 
     void needBackend() const {
         if (!ctx)
@@ -958,7 +1004,8 @@ class Scene {
     void prepareHostStructures() {
         if (meshes.empty())
             return;
-        bool tlas_dirty = h_tlasNodes.empty();
+        const bool synced = syncHostTrees(); // (trees the GPU refitted / rebuilt since the host last looked)
+        bool tlas_dirty = h_tlasNodes.empty() || synced;
         if (flatMeshes.size() != meshes.size()) {
             flatMeshes.assign(meshes.size(), ptrt_mesh_desc{});
             lastWorld.assign(meshes.size(), mat4());
@@ -1055,16 +1102,91 @@ class Scene {
         flat.env_height = env_height;
     }
 
+    // The dynamic-geometry policy (setDynamicGeometryPolicy): meshes whose vertices changed while their topology is what
+    // the device holds keep their uploaded tree.  Returns false when the commit has to take the reference's route.
+    bool commitOnGpu() {
+        if (dynPolicy == DynamicGeometryPolicy::HostRebuild || !gpu_resources_initialized || geometryDirty ||
+            uploadedFaces.size() != meshes.size() || flatMeshes.size() != meshes.size())
+            return false;
+        std::vector<size_t> moved;
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            const Mesh *m = meshes[i].get();
+            if (!m->bvhDirty && !m->vertsDirty)
+                continue;
+            const std::vector<Tri> &uf = uploadedFaces[i];
+            if (m->bvhNodes.empty() || m->vertices.size() != uploadedVerts[i] || m->faces.size() != uf.size() ||
+                std::memcmp(m->faces.data(), uf.data(), uf.size() * sizeof(Tri)) != 0)
+                return false;
+            moved.push_back(i);
+        }
+        if (moved.empty())
+            return false;
+        const bool rebuild = dynPolicy == DynamicGeometryPolicy::GpuRebuild;
+        for (size_t i : moved) {
+            Mesh *m = meshes[i].get();
+            check(ptrt_update_vertices(ctx, (int)i, &m->vertices[0].x, (int)m->vertices.size(), 0), "Failed to update vertices");
+            if (rebuild)
+                check(ptrt_build_bvh(ctx, (int)i), "Failed to build BVH");
+            m->bvhDirty = m->vertsDirty = false;
+            // 1: boxes to refit on the host; 2: the prim order must be read back first (it stays pending across later refits)
+            hostTreeStale[i] = rebuild ? 2 : (hostTreeStale[i] == 2 ? 2 : 1);
+            flatMeshes[i].verts = reinterpret_cast<const ptrt_vec3 *>(m->vertices.data()); // (the caller may have re-allocated them)
+            flatMeshes[i].faces = m->faces.data();
+        }
+        if (!rebuild)
+            check(ptrt_refit(ctx), "Failed to refit");
+        if (h_tlasNodes.size() > 1) { // a real TLAS is rebuilt on the host over the new boxes, as the reference's commit does
+            syncHostTrees();
+            syncTLAS();
+        }
+        ++gpuDynamicCommits;
+        return true;
+    }
+    // host copies of the trees the GPU refitted (boxes) or rebuilt (prim order, then boxes); true if any changed
+    bool syncHostTrees() {
+        bool any = false;
+        for (size_t i = 0; i < hostTreeStale.size() && i < meshes.size(); ++i) {
+            if (!hostTreeStale[i])
+                continue;
+            Mesh *m = meshes[i].get();
+            if (hostTreeStale[i] == 2 && ctx)
+                check(ptrt_read_prim_order(ctx, (int)i, m->bvhPrimIndices.data(), (int)m->bvhPrimIndices.size()),
+                      "Failed to read the prim order");
+            const bool bd = m->bvhDirty; // (a caller's later edit stays pending)
+            m->refitBVH();
+            m->bvhDirty = bd;
+            hostTreeStale[i] = 0;
+            any = true;
+        }
+        return any;
+    }
+
     void updateAccelerationStructures() {
         if (meshes.empty())
             return;
-        needBackend();
+        if (!ctx) { // host-only scene: the host half of a commit (trees, TLAS, material arrays); there is nothing to upload to
+            prepareHostStructures();
+            return;
+        }
+        commitOnGpu();
         prepareHostStructures();
         if (geometryDirty) {
             check(ptrt_upload_geometry(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,
                                        flat.tlas_mesh_indices, flat.tlas_index_count),
                   "Failed to upload geometry");
             geometryDirty = instancesDirty = false;
+            ++geometryUploads;
+            // what the device now holds, for the dynamic-geometry policy
+            uploadedFaces.resize(meshes.size());
+            uploadedVerts.resize(meshes.size());
+            hostTreeStale.assign(meshes.size(), 0);
+            for (size_t i = 0; i < meshes.size(); ++i) {
+                uploadedVerts[i] = meshes[i]->vertices.size();
+                if (dynPolicy != DynamicGeometryPolicy::HostRebuild)
+                    uploadedFaces[i] = meshes[i]->faces;
+                else
+                    uploadedFaces[i].clear(); // (the default policy pays nothing for the copies)
+            }
         } else if (instancesDirty) {
             check(ptrt_update_instances(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,
                                         flat.tlas_mesh_indices, flat.tlas_index_count),

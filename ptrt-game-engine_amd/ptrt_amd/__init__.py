@@ -186,6 +186,9 @@ _sig("hs_add_mesh_obj", C.c_int, _vp, C.c_char_p, _fp)
 _sig("hs_add_checkerboard", C.c_int, _vp, C.c_float, C.c_int, C.c_float, _fp, _fp)
 _sig("hs_mesh_op", C.c_int, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float)
 _sig("hs_mesh_set_vertices", C.c_int, _vp, C.c_int, _fp, C.c_int)
+_sig("hs_mesh_set_triangle_soup", C.c_int, _vp, C.c_int, _fp, C.c_int)
+_sig("hs_set_dynamic_geometry_policy", C.c_int, _vp, C.c_int)
+_sig("hs_commit_counts", C.c_int, _vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
 _sig("hs_mesh_counts", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("hs_add_point_light", None, _vp, _fp, _fp, C.c_float, C.c_float, C.c_float)
 _sig("hs_add_directional_light", None, _vp, _fp, _fp, C.c_float)
@@ -226,6 +229,7 @@ _sig("ptrt_denoiser_disable", C.c_int, _vp)
 _sig("ptrt_set_prev_view_proj", C.c_int, _vp, _fp)
 _sig("hs_refit_object_changes", C.c_int, _vp)
 _sig("hs_refit_from_device", C.c_int, _vp, C.c_int, _vp)
+_sig("hs_refit_from_host", C.c_int, _vp, C.c_int, _vp)
 _sig("ptrt_update_vertices", C.c_int, _vp, C.c_int, _fp, C.c_int, C.c_int)
 _sig("ptrt_refit", C.c_int, _vp)
 _sig("ptrt_build_bvh", C.c_int, _vp, C.c_int)
@@ -388,6 +392,23 @@ class Scene:
         a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         self._chk(lib.hs_mesh_set_vertices(self._h, mesh, _fptr(a), a.shape[0]))
 
+    def setTriangleSoup(self, mesh, tris):
+        """What the reference's updatePTScene does to a `Triangles` mesh (PTRTtransfer.cuh:2249-2270): vertices and faces
+        rewritten, bvhDirty / vertsDirty set, local box recomputed; the caller then commits (commitObjectChanges)."""
+        a = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+        self._chk(lib.hs_mesh_set_triangle_soup(self._h, mesh, _fptr(a), a.shape[0]))
+
+    POLICIES = {"HostRebuild": 0, "GpuRefit": 1, "GpuRebuild": 2}
+
+    def setDynamicGeometryPolicy(self, policy):
+        self._chk(lib.hs_set_dynamic_geometry_policy(self._h, self.POLICIES.get(policy, policy)))
+
+    def commitCounts(self):
+        """(commits that took the GPU refit / rebuild path, geometry uploads) so far."""
+        a, b = C.c_longlong(), C.c_longlong()
+        lib.hs_commit_counts(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def meshCounts(self, mesh):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._chk(lib.hs_mesh_counts(self._h, mesh, C.byref(a), C.byref(b), C.byref(c)))
@@ -465,6 +486,10 @@ class Scene:
     def refitFromDevice(self, mesh, device_ptr):
         """New vertex positions (n x 3 float32) already in device memory -> update + GPU refit, no host sync."""
         self._chk(lib.hs_refit_from_device(self._h, mesh, C.c_void_p(device_ptr)))
+
+    def refitFromHost(self, mesh, host_ptr):
+        """New positions from HOST memory (a raw address: pinned memory makes the copy asynchronous) + GPU refit."""
+        self._chk(lib.hs_refit_from_host(self._h, mesh, C.c_void_p(host_ptr)))
 
     def rebuildObjectChanges(self, sync_host_copy=True):
         """commitObjectChanges for unchanged face counts with the BVH rebuilt on the GPU (ptrt_build_bvh)."""

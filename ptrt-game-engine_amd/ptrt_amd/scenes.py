@@ -263,3 +263,73 @@ def many(scene, n=40, instanced=True, sphere_segments=5):
         else:
             scene.scale(m, tuple(rs.uniform(0.2, 0.5, 3)))
             scene.moveTo(m, pos)
+
+
+# ---- the reference's dynamic-geometry caller (src/common/PTRTtransfer.cuh) ------------------------------------------------
+# tools/refapp/transfer_probe.cpp compiles buildPTScene / updatePTScene / updatePTCamera of the reference in place over the
+# C++ mirror and runs them on a UnifiedScene; the functions below are the same scene and the same per-step changes through
+# this module's Scene API, call by call (tests/test_transfer_scenes.py holds the two to the same bytes).
+TRANSFER_CELLS, TRANSFER_SIZE = 12, (320, 180)
+
+
+def unified_material(albedo=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, **fields):
+    """toPTMaterial(UnifiedMaterial(albedo, roughness, metallic)) (PTRTtransfer.cuh:242-275, 2038-2060): every field is
+    assigned, so Material(alb, rough, met)'s transmission-roughness floor does not apply."""
+    one, t = np.float32(1.0), np.float32(metallic)
+    alb = np.asarray(albedo, dtype=np.float32)
+    m = Material()  # the defaults are UnifiedMaterial's
+    m.set("albedo", alb).set("roughness", roughness).set("metallic", metallic)
+    m.set("specular", (one - t) * np.float32(0.04) + t * alb)  # ::lerp(vec3(0.04f), albedo, metallic)
+    m.set("transmissionRoughness", 0.0)
+    for k, v in fields.items():
+        m.set(k, v)
+    return m
+
+
+def transfer_sheet(k, cells=TRANSFER_CELLS):
+    """transfer_probe.cpp's sheet(k): (cells^2 * 2, 9) float32, the same fp32 products and sums in the same order."""
+    f = np.float32
+    t = f(k)
+    i = np.arange(cells + 1, dtype=np.float32)
+    x, z = np.meshgrid(f(-3.0) + f(0.5) * i, f(-3.0) + f(0.5) * i, indexing="xy")  # x along i, z along j
+    a, b = x * z, x - z
+    y = (f(0.05) * a + (f(0.04) * t) * b) + (f(0.02) * t) * (x * x)
+    p = np.stack([x, y.astype(np.float32), z], axis=-1).astype(np.float32)
+    A, B = p[:-1, :-1], p[:-1, 1:]
+    C, D = p[1:, 1:], p[1:, :-1]
+    tris = np.stack([np.stack([A, C, B], axis=2), np.stack([A, D, C], axis=2)], axis=2)
+    return np.ascontiguousarray(tris.reshape(-1, 9), dtype=np.float32)
+
+
+def transfer_demo(scene):
+    """make_unified() + buildPTScene (PTRTtransfer.cuh:2120-2200): camera, leaf target, meshes in order (a `Triangles`
+    sheet, a DYNAMIC cube = an instance, a floor, a static sphere whose transform is baked: scale, rotate, moveTo), lights,
+    sky.  Returns the mesh indices (water, cube)."""
+    scene.setCamera((0.0, 3.0, 7.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 42.0, 0.0, 1.0)
+    scene.setBVHLeafTarget(4, 2)
+    water = scene.addTriangles(transfer_sheet(0), unified_material((0.2, 0.45, 0.8), 0.15, 0.0))
+    cube = scene.addCube(unified_material((1.0, 0.766, 0.336), 0.1, 1.0, specular=(1.0, 0.782, 0.344)))  # UnifiedMaterial::Gold
+    scene.setPosition(cube, (-1.5, 0.9, 0.5))
+    scene.setRotation(cube, (0.2, 0.4, 0.0))
+    scene.setInstanceScale(cube, (0.8, 0.8, 0.8))
+    scene.addPlaneXZ(-1.0, 6.0, unified_material((0.7, 0.7, 0.65), 0.9, 0.0))
+    ball = scene.addSphere(12, unified_material((0.8, 0.3, 0.25), 0.4, 0.0))
+    scene.scale(ball, (1.2, 0.9, 1.2))
+    scene.rotateSelfEulerXYZ(ball, (0.0, 0.3, 0.1))
+    scene.moveTo(ball, (1.6, 0.8, -0.5))
+    scene.addPointLight((0.0, 5.0, 2.0), (1.0, 0.95, 0.9), 40.0, 100.0, 0.3)
+    scene.addSpotLight((-3.0, 4.0, 3.0), (0.6, -0.8, -0.6), (0.6, 0.7, 1.0), 60.0, 0.3, 0.5, 50.0, 0.0)
+    scene.setSkyGradient((0.3, 0.5, 0.9), (0.9, 0.9, 1.0))
+    return water, cube
+
+
+def transfer_step(scene, water, cube, k):
+    """step(u, k) + updatePTScene + updatePTCamera (PTRTtransfer.cuh:2204-2393): the `Triangles` mesh's vertices and faces
+    rewritten with both dirty flags set, the dynamic cube's transform, commitObjectChanges(), then the camera."""
+    f = np.float32
+    scene.setTriangleSoup(water, transfer_sheet(k))
+    scene.setPosition(cube, (f(-1.5) + f(0.4) * f(k), 0.9, 0.5))
+    scene.setRotation(cube, (0.2, f(0.4) + f(0.3) * f(k), 0.0))
+    scene.setInstanceScale(cube, (0.8, 0.8, 0.8))
+    scene.commitObjectChanges()
+    scene.setCamera((f(0.5) * f(k), 3.0, 7.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 42.0, 0.0, 1.0)

@@ -54,6 +54,8 @@ struct KParams {
     // scene arena (device pointers)
     const float4 *mesh_recs;  // 12 float4 per mesh
     const float4 *nodes;      // 4 float4 per inner node (child pair)
+    const float4 *nodes2;     // NODE2_F4 float4 per inner node: the node, its left child's node, its right child's node (two levels
+                              // per fetch: expand_nodes_kernel derives them from `nodes` after every upload / refit / rebuild)
     const int2 *leaves;       // {first tri slot, count}
     const float4 *tris;       // 3 float4 per leaf slot: {v0, e1, e2}; the three w hold the geometric normal (tri_normals_kernel)
     const int4 *slot_face;    // per leaf slot: global vertex indices + face index
@@ -83,11 +85,13 @@ struct KParams {
     int n_nodes;        // inner nodes in the arena (the LDS-staged variant clamps its copies to them)
     int top_off;        // WG = 4 variant, A/B: do not read the staged nodes (isolates the cost of the larger workgroups)
     int n_tiles;        // 8x8-pixel tiles of this launch (the 4-wave variant's last workgroup may own fewer than 4)
-    int lds_extra;      // PMODE 1: byte offset in the launch's LDS of the staged shading inputs: the jitter table (16 float2),
-                        // the lanes' blue-noise values (64 float2), then what lds_flags names
-    int lds_flags;      // 0 = nothing staged; bit 2: the jitter inputs are; bit 0: the light records follow (n_lights <=
-                        // LDS_LIGHTS); bit 1: then the material records of the leaf's meshes, by mesh ORDER
+    int lds_extra;      // PMODE 1: byte offset in the workgroup's LDS of the staged shading inputs its waves share: the jitter
+                        // table (16 float2), then what lds_flags names
+    int lds_flags;      // 0 = nothing staged; bit 2: the jitter inputs are (the table, and per wave the lanes' blue-noise
+                        // values); bit 0: the light records follow the table (n_lights <= LDS_LIGHTS); bit 1: then the
+                        // material records of the leaf's meshes, by mesh ORDER
     int pair_cap;       // PMODE 4: entries the LDS pair list holds (a multiple of 64, >= 64 * pair_meshes + 64)
+    int lds_wave, lds_wave_bytes; // PMODE 1: byte offset of the first wave's own lists in the workgroup's LDS, and their stride
     // frame
     Camera cam;
     f3 sky_top, sky_bottom;
@@ -115,6 +119,7 @@ PT_DEV int global_row(int yl, int y0, int il_period, int il_phase) {
 }
 
 constexpr int MESH_REC_F4 = 12;
+constexpr int NODE2_F4 = 12;
 constexpr int TOP_LEVELS = 3;                    // BLAS levels numbered in level order (ptrt_capi.hip convert_tree)
 constexpr int TOP_NODES = (1 << TOP_LEVELS) - 1;  // ... = the first 7 inner nodes of a tree
 constexpr int TLAS_HEAD_F4 = 7; // {first-pass box, root}, {.., flags}, the three rows of the inverse matrix, and for an instance its LOCAL box
@@ -613,6 +618,26 @@ __global__ void tri_normals_kernel(float4 *__restrict__ tris, int n_slots) {
     tris[s * 3 + 0].w = gn.x;
     tris[s * 3 + 1].w = gn.y;
     tris[s * 3 + 2].w = gn.z;
+}
+
+// Two-level node records: record i = {node i, node of its left child, node of its right child} (an absent or leaf child's
+// part is zero), so that ONE fetch serves two steps of the binary walk -- the node's own child boxes, and then the boxes of
+// whichever child the walk enters next (see descend2 in pt_render.hip.h).  Derived from the canonical child-pair nodes, which
+// the refit / rebuild kernels keep writing; 192 B per inner node.
+__global__ void expand_nodes_kernel(const float4 *__restrict__ nodes, float4 *__restrict__ nodes2, int n_nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes * 3)
+        return;
+    const int n = i / 3, part = i % 3;
+    int src = n;
+    if (part) {
+        const float4 refs = nodes[n * 4 + 3];
+        src = __float_as_int(part == 1 ? refs.x : refs.y);
+    }
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        nodes2[n * NODE2_F4 + part * 4 + k] = src >= 0 ? nodes[src * 4 + k] : z;
 }
 
 // HitInfo of a hit (intersection.cuh:382-396, 466-478) from the triangle's geometric normal and its mesh's flags

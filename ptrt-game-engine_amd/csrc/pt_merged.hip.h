@@ -212,6 +212,11 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);
+                if (PT_TWO_LEVEL) { // (any-hit pairs walk like closest-hit ones here, with a fixed limit)
+                    if (descend2(K.nodes2, stk, sp, pr, tb, cur))
+                        pop();
+                    continue;
+                }
                 const float4 n0 = K.nodes[cur * 4 + 0], n1 = K.nodes[cur * 4 + 1], n2 = K.nodes[cur * 4 + 2],
                              n3 = K.nodes[cur * 4 + 3];
                 float tL, tR;

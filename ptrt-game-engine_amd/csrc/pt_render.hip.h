@@ -110,6 +110,35 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     return l;
 }
 
+// PMODE 1 (every BLAS one leaf, the scene's triangles in LDS).  A workgroup of WG waves = WG neighbouring tiles shares ONE copy
+// of what is read-only -- triangle packets, mesh table, mesh heads, jitter table, light and material records -- and each
+// wave has its own lists behind it: the rays' minima / flags, the pair list, the lanes' blue-noise values, the ray totals.
+// Layout (host: pm1_layout in ptrt_capi.hip): [tris + pads | meshtab | meshbox] [lds_extra: jit | lights | mats]
+// [lds_wave + wave * lds_wave_bytes: best 512 | pairs 128 * meshes | bn 512 (if staged) | count 16].
+PT_DEV PairLds carve_pm1(void *base, const KParams &K, int wave) {
+    PairLds l{};
+    char *p = (char *)base;
+    const int meshes = K.pair_meshes;
+    l.tris = (float4 *)p;
+    p += (size_t)K.pair_tri_slots * 48 + (size_t)meshes * PAIR_PAD * 16;
+    l.meshtab = (int4 *)p;
+    p += (size_t)meshes * 16;
+    l.meshbox = (float4 *)p;
+    char *x = (char *)base + K.lds_extra;
+    l.jit = (const float2 *)x;
+    l.lights = (const float4 *)(x + 16 * 8);
+    l.mats = l.lights + ((K.lds_flags & 1) ? K.n_lights * 4 : 0);
+    char *w = (char *)base + K.lds_wave + wave * K.lds_wave_bytes;
+    l.best = (unsigned long long *)w;
+    l.occ = (uint32_t *)(w + 256); // (the any-hit flags take the second half of the minima's words)
+    l.pairs = (uint32_t *)(w + 512);
+    w += 512 + (size_t)meshes * 128;
+    l.bn = (const float2 *)w;
+    w += (K.lds_flags & 4) ? 64 * 8 : 0;
+    l.count = (unsigned long long *)w;
+    return l;
+}
+
 // PMODE 2 in 256-thread workgroups (path_trace_kernel<.., WG = 4>): mesh table, mesh heads and the top levels of every
 // BLAS are ONE copy per workgroup at the base of its LDS; behind them each wave has its own lists and stacks.
 PT_DEV size_t shared_lds_bytes(int meshes) { return (size_t)meshes * (32 + TOP_NODES * 64); }
@@ -472,6 +501,79 @@ PT_DEV void fetch_node(const KParams &K, const PairLds &L, int cur, int local, i
     }
 }
 
+// Two steps of the binary near-first walk (bvh_trace_local, intersection.cuh:344-435) from ONE two-level record
+// (expand_nodes_kernel): the node's child boxes, then -- if the walk enters an inner child -- that child's child boxes, which
+// the reference would test in its next iteration with the same limit `tb` (no leaf is visited in between, so the limit
+// cannot have moved).  Pushes are the binary walk's, in its order: the far child with its entry distance (E1), then the far
+// grandchild.  Afterwards `cur` is a leaf or a node two levels down; returns true when neither child (or neither
+// grandchild) can hold a closer hit: the caller pops.  Same culling, same tie order, half the dependent round trips.
+#ifndef PT_TWO_LEVEL
+#define PT_TWO_LEVEL 0 // measured (showcase 3.878 vs 3.888 ms, 1 M triangles 1.226 vs 1.200, fluid 0.975 vs 0.983): a build option
+#endif
+PT_DEV bool descend2(const float4 *__restrict__ nodes2, LdsStack stk, int &sp, const RayO &pr, float tb, int &cur) {
+    const float4 *rec = nodes2 + (size_t)cur * NODE2_F4;
+    const float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+    float tL, tR;
+    const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tb, tL);
+    const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tb, tR);
+    if (!(hL || hR))
+        return true;
+    const bool nearL = hL && (!hR || tL <= tR);
+    const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+    if (nearL ? hR : hL) {
+        stk.push(sp, nearL ? Rr : Lr, nearL ? tR : tL);
+        ++sp;
+    }
+    cur = nearL ? Lr : Rr;
+    if (cur < 0)
+        return false;
+    const float4 *g = rec + (nearL ? 4 : 8);
+    const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+    const bool hGL = slab(mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), pr, tb, tL);
+    const bool hGR = slab(mk3(g1.z, g1.w, g2.x), mk3(g2.y, g2.z, g2.w), pr, tb, tR);
+    if (!(hGL || hGR))
+        return true;
+    const bool nearGL = hGL && (!hGR || tL <= tR);
+    const int GLr = __float_as_int(g3.x), GRr = __float_as_int(g3.y);
+    if (nearGL ? hGR : hGL) {
+        stk.push(sp, nearGL ? GRr : GLr, nearGL ? tR : tL);
+        ++sp;
+    }
+    cur = nearGL ? GLr : GRr;
+    return false;
+}
+// the any-hit walk's two steps (bvh_any_hit_local, intersection.cuh:300-341: no ordering, the right child waits on the stack)
+PT_DEV bool descend2_any(const float4 *__restrict__ nodes2, LdsStack stk, int &sp, const RayO &pr, float tm, int &cur) {
+    const float4 *rec = nodes2 + (size_t)cur * NODE2_F4;
+    const float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+    float tL, tR;
+    const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), pr, tm, tL);
+    const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), pr, tm, tR);
+    if (!(hL || hR))
+        return true;
+    const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+    if (hL && hR) {
+        stk.push(sp, Rr, 0.0f);
+        ++sp;
+    }
+    cur = hL ? Lr : Rr;
+    if (cur < 0)
+        return false;
+    const float4 *g = rec + (hL ? 4 : 8);
+    const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+    const bool hGL = slab(mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), pr, tm, tL);
+    const bool hGR = slab(mk3(g1.z, g1.w, g2.x), mk3(g2.y, g2.z, g2.w), pr, tm, tR);
+    if (!(hGL || hGR))
+        return true;
+    const int GLr = __float_as_int(g3.x), GRr = __float_as_int(g3.y);
+    if (hGL && hGR) {
+        stk.push(sp, GRr, 0.0f);
+        ++sp;
+    }
+    cur = hGL ? GLr : GRr;
+    return false;
+}
+
 // drains the pair queue [0, P): afterwards L.best[r] = min over ray r's pairs of {t bits, order << 24 | slot}
 template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
     LdsStack stk{L.stack + lane};
@@ -538,6 +640,11 @@ template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLd
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);
+                if (PT_TWO_LEVEL && !L.topnodes) {
+                    if (descend2(K.nodes2, stk, sp, pr, tb, cur))
+                        pop();
+                    continue;
+                }
                 float4 n0, n1, n2, n3;
                 fetch_node(K, L, cur, cur - rootref, oi, n0, n1, n2, n3);
                 float tL, tR;
@@ -806,6 +913,11 @@ template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);
+                if (PT_TWO_LEVEL && !L.topnodes) {
+                    if (descend2_any(K.nodes2, stk, sp, pr, tm, cur))
+                        pop();
+                    continue;
+                }
                 float4 n0, n1, n2, n3;
                 fetch_node(K, L, cur, cur - rootref, oi, n0, n1, n2, n3);
                 float tL, tR;
@@ -1213,25 +1325,69 @@ namespace pt {
 #ifndef PT_WAVES_PMODE1
 #define PT_WAVES_PMODE1 5
 #endif
-constexpr int waves_per_simd(int pmode, bool full) { return (pmode == 1 && !full) ? PT_WAVES_PMODE1 : PT_WAVES_PER_EU; }
+// Two tiles per workgroup (WG = 2) halve what a wave costs in LDS for the shared copies: the small scene then fits SIX waves
+// per SIMD (80 VGPRs, 16 of them spilled) -- 24 waves per CU instead of 20.
+#ifndef PT_WAVES_PMODE1_WG2
+#define PT_WAVES_PMODE1_WG2 6
+#endif
+constexpr int waves_per_simd(int pmode, bool full, int wg = 1) {
+    return (pmode == 1 && !full) ? (wg == 2 ? PT_WAVES_PMODE1_WG2 : PT_WAVES_PMODE1) : PT_WAVES_PER_EU;
+}
 // LDS a one-wave workgroup may use without lowering that occupancy: a CU has 160 KB, allocated in 1280-byte granules
 // (measured: Cornell at 7,680 B runs 20 waves per CU, at 7,744 B visibly fewer; showcase at 10,192 B 16, at 10,384 B fewer)
 constexpr int LDS_GRANULE = 1280;
-constexpr int lds_per_wave(int pmode, bool full) { return 160 * 1024 / (4 * waves_per_simd(pmode, full)) / LDS_GRANULE * LDS_GRANULE; }
+constexpr int lds_per_wave(int pmode, bool full, int wg = 1) { return 160 * 1024 / (4 * waves_per_simd(pmode, full, wg)) / LDS_GRANULE * LDS_GRANULE; }
+// (a workgroup of wg waves may use wg times that: the granule rounding applies to the workgroup's total)
+constexpr int lds_per_workgroup(int pmode, bool full, int wg) { return 160 * 1024 / (4 * waves_per_simd(pmode, full, wg) / wg) / LDS_GRANULE * LDS_GRANULE; }
 // PMODE 0: lock-step mesh loop; 1: pair compaction, single-leaf BLASes (triangles staged in LDS);
 //       2: pair compaction, general BLASes (per-lane traversal, LDS stacks); 3: the same behind a real TLAS, in rounds;
 //       4: as 2 with ONE traversal per iteration: a light sample's shadow ray rides with the next extension ray
 //          (pt_merged.hip.h)
 //  WG: waves per workgroup.  1 = one 8x8 tile per workgroup.  4 (PMODE 2 only, option lds_nodes): four tiles per
 //      workgroup that share one LDS copy of the mesh heads and of the top TOP_LEVELS levels of every BLAS.
+typedef const __attribute__((address_space(4))) KParams *kparams_ptr;
+PT_DEV const KParams &kparams(kparams_ptr p) {
+    asm volatile("" : "+s"(p));
+    return *(const KParams *)p;
+}
 template <int GEOM, bool FULL, int PMODE, int WG = 1>
-__global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_per_simd(PMODE, FULL), 8))) void path_trace_kernel(const KParams K) {
+__global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_per_simd(PMODE, FULL, WG), 8))) void path_trace_kernel(const KParams Kin) {
+    // The parameters are read where they are used, through the kernarg segment itself (scalar loads that hit the constant
+    // cache), not out of the by-value copy: ~110 dwords of pointers, camera and options held in SGPRs across the persistent
+    // loop were what the kernel spilled -- 93 scalar registers parked in VGPR lanes and ~115 v_readlane per iteration.  Each
+    // phase gets its own OPAQUE copy of the pointer (kparams: an empty asm the compiler cannot see through), so a field's
+    // live range ends with the phase that reads it.
+    (void)Kin;
+    const kparams_ptr kp0 = (kparams_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const KParams &K = kparams(kp0); // set-up and epilogue
     extern __shared__ uint2 lds_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LdsStack stk{lds_raw + lane};
     PairLds PL{};
     constexpr bool MERGED = (PMODE == 4);
-    if (WG > 1) {
+    if (PMODE == 1) {
+        PL = carve_pm1((void *)lds_raw, K, wave);
+        const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+        // mesh i's packets start PAIR_PAD * i float4 later than in the arena: with 48-B packets the per-mesh blocks would
+        // otherwise sit a multiple of 16 banks apart and lanes working on different meshes would collide on ds_read_b128
+        for (int i = 0; i < K.pair_meshes; ++i) {
+            const int m = K.tlas_mesh_ids[lf.x + i];
+            const int2 leaf = K.leaves[~__float_as_int(K.mesh_recs[m * MESH_REC_F4].w)];
+            for (int k = threadIdx.x; k < leaf.y * 3; k += 64 * WG)
+                PL.tris[leaf.x * 3 + i * PAIR_PAD + k] = K.tris[leaf.x * 3 + k];
+        }
+        for (int i = threadIdx.x; i < K.pair_meshes; i += 64 * WG) {
+            const int m = K.tlas_mesh_ids[lf.x + i];
+            const MeshHead mh = load_mesh_head(K, m);
+            PL.meshbox[2 * i] = K.mesh_recs[m * MESH_REC_F4 + 0];
+            float4 hb = K.mesh_recs[m * MESH_REC_F4 + 1];
+            hb.w = __int_as_float((mh.flags & 0xff) | (m << 8)); // (flags and mesh id in one word: staged_mesh_head)
+            PL.meshbox[2 * i + 1] = hb;
+            const int2 leaf = K.leaves[~mh.root_ref];
+            PL.meshtab[i] = make_int4(leaf.x, leaf.y, mh.flags, m);
+        }
+        // (the barrier follows the shading inputs, below)
+    } else if (WG > 1) {
         PL = carve_pair_lds_wg((void *)lds_raw, wave, K.pair_meshes, K.stack_entries);
         const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
         for (int i = threadIdx.x; i < K.pair_meshes; i += 64 * WG) {
@@ -1255,21 +1411,9 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (K.top_off)
             PL.topnodes = nullptr;
     } else if (PMODE) {
-        const int staged = (PMODE == 1) ? K.pair_tri_slots : 0;
-        PL = carve_pair_lds((void *)lds_raw, staged, PMODE == 3 ? 0 : K.pair_meshes, PMODE >= 2 ? K.stack_entries : 0,
+        PL = carve_pair_lds((void *)lds_raw, 0, PMODE == 3 ? 0 : K.pair_meshes, K.stack_entries,
                             PMODE == 3 ? K.tlas_max_leaf : 0, PMODE == 3 ? K.tlas_depth : 0, MERGED ? K.pair_cap : 0);
         const int2 lf = PMODE == 3 ? make_int2(0, 0) : K.tlas_leaves[~K.tlas_root_ref];
-        if (PMODE == 1) {
-            // mesh i's packets start 2*i float4 (32 B) later than in the arena: with 48-B packets
-            // the per-mesh blocks would otherwise sit a multiple of 16 banks apart and lanes working
-            // on different meshes would collide on ds_read_b128 (PAIR_PAD)
-            for (int i = 0; i < K.pair_meshes; ++i) {
-                const int m = K.tlas_mesh_ids[lf.x + i];
-                const int2 leaf = K.leaves[~__float_as_int(K.mesh_recs[m * MESH_REC_F4].w)];
-                for (int k = lane; k < leaf.y * 3; k += 64)
-                    PL.tris[leaf.x * 3 + i * PAIR_PAD + k] = K.tris[leaf.x * 3 + k];
-            }
-        }
         for (int i = lane; PMODE != 3 && i < K.pair_meshes; i += 64) {
             const int m = K.tlas_mesh_ids[lf.x + i];
             const MeshHead mh = load_mesh_head(K, m);
@@ -1277,17 +1421,16 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             float4 hb = K.mesh_recs[m * MESH_REC_F4 + 1];
             hb.w = __int_as_float((mh.flags & 0xff) | (m << 8)); // (flags and mesh id in one word: staged_mesh_head)
             PL.meshbox[2 * i + 1] = hb;
-            if (PMODE == 1) {
-                const int2 leaf = K.leaves[~mh.root_ref];
-                PL.meshtab[i] = make_int4(leaf.x, leaf.y, mh.flags, m);
-            }
         }
         __syncthreads();
     }
     const int tile = WG > 1 ? blockIdx.x * WG + wave : blockIdx.x;
-    if (WG > 1 && tile >= K.n_tiles)
+    // (a larger workgroup's last tiles may not exist: such a wave takes part in the staging and the barrier with a tile
+    // outside the frame -- `inside` is false for all its lanes -- and leaves before the loop)
+    const bool no_tile = WG > 1 && tile >= K.n_tiles;
+    if (PMODE != 1 && no_tile)
         return; // (after the workgroup's only barrier)
-    const int tx = tile % K.tiles_x, ty = tile / K.tiles_x;
+    const int tx = no_tile ? 0 : tile % K.tiles_x, ty = no_tile ? 0 : tile / K.tiles_x;
     // Registers are what this kernel runs out of (128 per lane at four waves per SIMD; what does not fit is spilled to
     // scratch, and a reload is a trip to the L2).  State that is only touched when a path starts or ends stays out of
     // them: the pixel's coordinates are recomputed from the lane id where they are needed (the empty asm keeps the
@@ -1304,48 +1447,46 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         asm volatile("" : "+v"(l));
         return ty * 8 + (l >> 3);
     };
-    auto pidx = [&]() { return (size_t)pyl() * K.width + px(); };
+    auto pidx = [&](int width) { return (size_t)pyl() * width + px(); };
     const bool inside = (px() < K.width) && (pyl() < K.rows);
-    const size_t npix = K.rng_plane;
     // PMODE 1 (a scene small enough for its triangles to sit in LDS): what the shading phases would otherwise fetch from
     // global memory in every iteration is staged too -- the jitter table and the lane's blue-noise value for [A], the light
     // records for [C], the material records by mesh order; [A], [C], [C2] and [E] then read no global memory.  Worth 2 %
     // (Cornell 2.27 -> 2.23 ms), and only while the workgroup's LDS stays within 10 KB: the kernel runs 16 waves per CU on
     // registers, one wave less costs 6.5 % -- which is why the modes whose stacks fill that budget do not stage (measured:
     // showcase +9 % with 64 bytes too many).
-    constexpr bool STAGED = (PMODE == 1) && (WG == 1);
+    constexpr bool STAGED = (PMODE == 1);
     bool lights_lds = false, mats_lds = false, jit_lds = false;
-    if (STAGED && K.lds_flags) { // (0: the launch has no room for them)
-        char *x = (char *)lds_raw + K.lds_extra;
-        float2 *jit = (float2 *)x, *bn = (float2 *)(x + 16 * 8);
-        float4 *lights = (float4 *)(x + LDS_EXTRA_FIXED), *mats = lights + ((K.lds_flags & 1) ? K.n_lights * 4 : 0);
-        if (lane < 16)
-            jit[lane] = taa_table_entry(lane);
-        {
-            const int x0 = px(), y0 = global_row(pyl(), K.y0, K.il_period, K.il_phase);
-            bn[lane] = K.blue_noise[(y0 & 63) * 64 + (x0 & 63)];
+    if (STAGED) {
+        if (K.lds_flags) { // (0: the launch has no room for them)
+            float2 *jit = const_cast<float2 *>(PL.jit), *bn = const_cast<float2 *>(PL.bn);
+            float4 *lights = const_cast<float4 *>(PL.lights), *mats = const_cast<float4 *>(PL.mats);
+            if (threadIdx.x < 16)
+                jit[threadIdx.x] = taa_table_entry(threadIdx.x);
+            {
+                const int x0 = px(), y0 = global_row(pyl(), K.y0, K.il_period, K.il_phase);
+                bn[lane] = K.blue_noise[(y0 & 63) * 64 + (x0 & 63)];
+            }
+            lights_lds = (K.lds_flags & 1) != 0;
+            jit_lds = (K.lds_flags & 4) != 0;
+            mats_lds = (K.lds_flags & 2) != 0;
+            if (lights_lds)
+                for (int i = threadIdx.x; i < K.n_lights * 4; i += 64 * WG)
+                    lights[i] = K.lights[i];
+            if (mats_lds) {
+                const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
+                for (int i = threadIdx.x; i < K.pair_meshes * 6; i += 64 * WG)
+                    mats[i] = K.materials[K.tlas_mesh_ids[lf.x + i / 6] * 6 + i % 6];
+            }
         }
-        lights_lds = (K.lds_flags & 1) != 0;
-        jit_lds = (K.lds_flags & 4) != 0;
-        mats_lds = (PMODE == 1) && (K.lds_flags & 2) != 0;
-        if (lights_lds)
-            for (int i = lane; i < K.n_lights * 4; i += 64)
-                lights[i] = K.lights[i];
-        if (mats_lds) {
-            const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
-            for (int i = lane; i < K.pair_meshes * 6; i += 64)
-                mats[i] = K.materials[K.tlas_mesh_ids[lf.x + i / 6] * 6 + i % 6];
-        }
-        PL.jit = jit;
-        PL.bn = bn;
-        PL.lights = lights;
-        PL.mats = mats;
-        __syncthreads();
+        __syncthreads(); // the workgroup's only barrier: triangles, tables and shading inputs are in place
+        if (no_tile)
+            return;
     }
 
     Rng rng = {0, 0, 0, 0, 0, 0};
     if (inside) {
-        const size_t idx = pidx();
+        const size_t idx = pidx(K.width), npix = K.rng_plane;
         rng.d = K.rng[idx];
         rng.v0 = K.rng[npix + idx];
         rng.v1 = K.rng[2 * npix + idx];
@@ -1359,7 +1500,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     // The pair modes have no scalar registers to spare: two loop-carried counters ended up in a VGPR lane that itself lived in
     // scratch -- a load, a v_writelane and a store per iteration (0.5 GB of writes per 1080p Cornell frame at five waves per
     // SIMD).  The totals sit in LDS instead, one 64-bit add per iteration: {extension rays, shadow rays << 32}.
-    constexpr bool LDS_COUNT = (PMODE >= 1) && (WG == 1);
+    constexpr bool LDS_COUNT = (PMODE >= 1) && (WG == 1 || PMODE == 1);
     unsigned long long *lds_count = LDS_COUNT ? PL.count : nullptr;
     if (LDS_COUNT) {
         if (lane == 0)
@@ -1381,8 +1522,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     CycleAcc cyc;
     PL.cyc = &cyc;
     const unsigned long long t_kernel = TS_NOW();
-    while (__builtin_amdgcn_ballot_w64(s < K.spp || (MERGED && pending))) {
-        const bool live = s < K.spp;
+    for (;;) {
+        const KParams &KL = kparams(kp0);
+        if (!__builtin_amdgcn_ballot_w64(s < KL.spp || (MERGED && pending)))
+            break;
+        const bool live = s < KL.spp;
 #ifdef PT_TRAV_STATS
         {
             const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
@@ -1393,29 +1537,30 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         }
 #endif
         PT_MARK("A");
+        const KParams &KA = kparams(kp0);
         const unsigned long long t_pa = TS_NOW();
         // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
         if (live && fresh) {
-            const int x = px(), y = global_row(pyl(), K.y0, K.il_period, K.il_phase);
+            const int x = px(), y = global_row(pyl(), KA.y0, KA.il_period, KA.il_phase);
             float tjx, tjy, bnx, bny;
             if (STAGED && jit_lds) {
-                const float2 e = lds_ld2(PL.jit, (K.frame_count + s) % 16);
+                const float2 e = lds_ld2(PL.jit, (KA.frame_count + s) % 16);
                 tjx = e.x;
                 tjy = e.y;
                 int l = lane;
                 asm volatile("" : "+v"(l));
-                blue_noise_shift(lds_ld2(PL.bn, l), K.frame_count + s, bnx, bny);
+                blue_noise_shift(lds_ld2(PL.bn, l), KA.frame_count + s, bnx, bny);
             } else {
-                taa_jitter(K.frame_count + s, tjx, tjy);
-                blue_noise_jitter(K.blue_noise, x, y, K.frame_count + s, bnx, bny);
+                taa_jitter(KA.frame_count + s, tjx, tjy);
+                blue_noise_jitter(KA.blue_noise, x, y, KA.frame_count + s, bnx, bny);
             }
             const float jitter_x = tjx + (bnx - 0.5f) * 0.25f;
             const float jitter_y = tjy + (bny - 0.5f) * 0.25f;
-            const float u = ((float)x + 0.5f + jitter_x) / (float)K.width;
-            const float v = 1.0f - ((float)y + 0.5f + jitter_y) / (float)K.height;
-            if (K.cam.lens_radius <= 0) {
-                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin;
-                ro = K.cam.origin;
+            const float u = ((float)x + 0.5f + jitter_x) / (float)KA.width;
+            const float v = 1.0f - ((float)y + 0.5f + jitter_y) / (float)KA.height;
+            if (KA.cam.lens_radius <= 0) {
+                const f3 dir = KA.cam.llc + u * KA.cam.horizontal + v * KA.cam.vertical - KA.cam.origin;
+                ro = KA.cam.origin;
                 rd = normalize(dir);
             } else {
                 f3 p;
@@ -1424,10 +1569,10 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     const float b = rng_uniform(rng);
                     p = 2.0f * mk3(a, b, 0.0f) - mk3(1.0f, 1.0f, 0.0f);
                 } while (dot(p, p) >= 1.0f);
-                const f3 rdisk = K.cam.lens_radius * p;
-                const f3 offset = K.cam.u * rdisk.x + K.cam.v * rdisk.y;
-                const f3 dir = K.cam.llc + u * K.cam.horizontal + v * K.cam.vertical - K.cam.origin - offset;
-                ro = K.cam.origin + offset;
+                const f3 rdisk = KA.cam.lens_radius * p;
+                const f3 offset = KA.cam.u * rdisk.x + KA.cam.v * rdisk.y;
+                const f3 dir = KA.cam.llc + u * KA.cam.horizontal + v * KA.cam.vertical - KA.cam.origin - offset;
+                ro = KA.cam.origin + offset;
                 rd = normalize(dir);
             }
             ray_spec = true;
@@ -1442,13 +1587,14 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(8, t_pa);
         PT_MARK("B");
+        const KParams &KB = kparams(kp0);
         // ---- [B] closest hit, all live lanes together (PMODE 4: and the parked shadow rays in the same traversal)
         Hit h;
         int h_order = 0; // PMODE 1: the hit mesh's place in the leaf (what the staged tables are indexed by)
         if (MERGED) {
             bool blocked = false;
             const unsigned long long t_tr = TS_NOW();
-            trace_merged(K, PL, lane, live, ro, rd, pending, park_o, park_d, park_tmax, h, blocked, cyc);
+            trace_merged(KB, PL, lane, live, ro, rd, pending, park_o, park_d, park_tmax, h, blocked, cyc);
             TS_ADD(12, t_tr);
             if (pending && !blocked)
                 acc = acc + pend; // the light sample of the previous vertex (path_logic.cuh:840-867), in its place
@@ -1461,14 +1607,15 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             }
         } else {
             const unsigned long long t_tr = TS_NOW();
-            h = (PMODE == 1)   ? closest_hit_pairs(K, PL, lane, live, ro, rd, h_order)
-                : (PMODE == 2) ? closest_hit_pairs_dyn(K, PL, lane, live, ro, rd)
-                : (PMODE == 3) ? closest_hit_pairs_tlas(K, PL, lane, live, ro, rd, cyc)
-                               : closest_hit<GEOM>(K, live, ro, rd, stk);
+            h = (PMODE == 1)   ? closest_hit_pairs(KB, PL, lane, live, ro, rd, h_order)
+                : (PMODE == 2) ? closest_hit_pairs_dyn(KB, PL, lane, live, ro, rd)
+                : (PMODE == 3) ? closest_hit_pairs_tlas(KB, PL, lane, live, ro, rd, cyc)
+                               : closest_hit<GEOM>(KB, live, ro, rd, stk);
             TS_ADD(12, t_tr);
         }
 
         PT_MARK("C");
+        const KParams &KC = kparams(kp0);
         const unsigned long long t_pc = TS_NOW();
         // ---- [C] first half of the shading
         bool end_path = false, shaded = false, want_shadow = false;
@@ -1483,23 +1630,23 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (live) {
             if (h.mesh < 0) {
                 if (bounce == 0 && s == 0) { // G-buffer of the first sample's first hit (scene_kernels.cuh:181-193)
-                    const size_t idx = pidx();
-                    K.normal[idx * 3 + 0] = 0.0f;
-                    K.normal[idx * 3 + 1] = 0.0f;
-                    K.normal[idx * 3 + 2] = 0.0f;
-                    K.depth[idx] = 1e30f;
-                    K.object_id[idx] = -1;
+                    const size_t idx = pidx(KC.width);
+                    KC.normal[idx * 3 + 0] = 0.0f;
+                    KC.normal[idx * 3 + 1] = 0.0f;
+                    KC.normal[idx * 3 + 2] = 0.0f;
+                    KC.depth[idx] = 1e30f;
+                    KC.object_id[idx] = -1;
                 }
-                if (K.use_sky) { // sampleSky (render_utils.cuh:115-137): gradient, or the equirect map
-                    if (K.env) {
+                if (KC.use_sky) { // sampleSky (render_utils.cuh:115-137): gradient, or the equirect map
+                    if (KC.env) {
                         const float phi = det_atan2(rd.z, rd.x);
                         const float theta = det_acos(max_(-1.0f, min_(1.0f, rd.y)));
                         const float u = (phi + PI_F) * (1.0f / TWO_PI_F);
                         const float v = theta * (1.0f / PI_F);
-                        acc = acc + throughput * tex2d_env(K.env, K.env_w, K.env_h, u, v);
+                        acc = acc + throughput * tex2d_env(KC.env, KC.env_w, KC.env_h, u, v);
                     } else {
                         const float t = 0.5f * (rd.y + 1.0f);
-                        acc = acc + throughput * lerp(K.sky_bottom, K.sky_top, t);
+                        acc = acc + throughput * lerp(KC.sky_bottom, KC.sky_top, t);
                     }
                 } else {
                     acc = acc + throughput * mk3(0.0f);
@@ -1512,25 +1659,25 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     const f3 gn = mk3(lds_ld1((const float *)PL.tris, ti + 3), lds_ld1((const float *)PL.tris, ti + 7),
                                       lds_ld1((const float *)PL.tris, ti + 11));
                     const int fl = __float_as_int(lds_ld1((const float *)PL.meshtab, h_order * 4 + 2));
-                    hit = make_surface_of(K, h, gn, fl, ro, rd, nullptr);
+                    hit = make_surface_of(KC, h, gn, fl, ro, rd, nullptr);
                 } else {
-                    hit = make_surface(K, h, ro, rd, nullptr, nullptr);
+                    hit = make_surface(KC, h, ro, rd, nullptr, nullptr);
                 }
                 if (bounce == 0 && s == 0) {
-                    const size_t idx = pidx();
-                    K.normal[idx * 3 + 0] = hit.normal.x;
-                    K.normal[idx * 3 + 1] = hit.normal.y;
-                    K.normal[idx * 3 + 2] = hit.normal.z;
-                    K.depth[idx] = hit.t;
-                    K.object_id[idx] = h.mesh;
+                    const size_t idx = pidx(KC.width);
+                    KC.normal[idx * 3 + 0] = hit.normal.x;
+                    KC.normal[idx * 3 + 1] = hit.normal.y;
+                    KC.normal[idx * 3 + 2] = hit.normal.z;
+                    KC.depth[idx] = hit.t;
+                    KC.object_id[idx] = h.mesh;
                 }
                 float4 m0, m2;
                 if (mats_lds) {
                     m0 = lds_ld4(PL.mats, h_order * 6 + 0);
                     m2 = lds_ld4(PL.mats, h_order * 6 + 2);
                 } else {
-                    m0 = K.materials[h.mesh * 6 + 0];
-                    m2 = K.materials[h.mesh * 6 + 2];
+                    m0 = KC.materials[h.mesh * 6 + 0];
+                    m2 = KC.materials[h.mesh * 6 + 2];
                 }
                 if (!hit.front_face) { // Beer-Lambert on back faces (path_logic.cuh:823-829)
                     const f3 T_unit = mk3(max_(1e-6f, m0.x), max_(1e-6f, m0.y), max_(1e-6f, m0.z));
@@ -1542,12 +1689,12 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                         acc = acc + throughput * mk3(m2.x, m2.y, m2.z);
                 }
                 // light sample of next-event estimation (path_logic.cuh:305-382, 840)
-                if (!ray_spec && K.n_lights > 0) {
+                if (!ray_spec && KC.n_lights > 0) {
                     float r = rng_uniform(rng);
                     r = min_(r, 0.99999994f);
-                    const int light_index = (int)(r * (float)K.n_lights);
-                    const LightRec light = lights_lds ? load_light<true>(PL.lights, light_index) : load_light(K.lights, light_index);
-                    const float pdf_pick = 1.0f / (float)K.n_lights;
+                    const int light_index = (int)(r * (float)KC.n_lights);
+                    const LightRec light = lights_lds ? load_light<true>(PL.lights, light_index) : load_light(KC.lights, light_index);
+                    const float pdf_pick = 1.0f / (float)KC.n_lights;
                     float attenuation = 1.0f;
                     float light_dist = 1e30f;
                     const f3 light_radiance = light.color * light.intensity;
@@ -1605,6 +1752,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(9, t_pc);
         PT_MARK("C2");
+        const KParams &KC2 = kparams(kp0);
         const unsigned long long t_pc2 = TS_NOW();
         // ---- [C2] the light sample's value, BEFORE its visibility is known (path_logic.cuh:840-867: bsdf * radiance *
         // attenuation / pdf, soft clamp, MIS weight): `lit_now = throughput * direct * wgt` is what a visible sample adds
@@ -1616,7 +1764,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (want_shadow) {
             int mi = mats_lds ? h_order : h.mesh;
             asm volatile("" : "+v"(mi)); // (its own fetch of the material: not 22 registers live across the shadow phase)
-            const Material mat = mats_lds ? load_material<true>(PL.mats, mi) : load_material(K.materials, mi);
+            const Material mat = mats_lds ? load_material<true>(PL.mats, mi) : load_material(KC2.materials, mi);
             const f3 V = -rd;
             const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
             if (pdf_sample > 0.0f) {
@@ -1649,6 +1797,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(10, t_pc2);
         PT_MARK("D");
+        const KParams &KD = kparams(kp0);
         // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas); PMODE 4 parks them instead and
         // walks them with the next extension rays
         const unsigned long long t_sh = TS_NOW();
@@ -1661,20 +1810,21 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 pending = true;
             }
         } else if (__builtin_amdgcn_ballot_w64(lit)) {
-            const bool in_shadow = (PMODE == 1)   ? any_hit_pairs(K, PL, lane, lit, shadow_o, L, shadow_tmax)
-                                   : (PMODE == 2) ? any_hit_pairs_dyn(K, PL, lane, lit, shadow_o, L, shadow_tmax)
-                                   : (PMODE == 3) ? any_hit_pairs_tlas(K, PL, lane, lit, shadow_o, L, shadow_tmax, cyc)
-                                                  : any_hit<GEOM>(K, lit, shadow_o, L, shadow_tmax, stk);
+            const bool in_shadow = (PMODE == 1)   ? any_hit_pairs(KD, PL, lane, lit, shadow_o, L, shadow_tmax)
+                                   : (PMODE == 2) ? any_hit_pairs_dyn(KD, PL, lane, lit, shadow_o, L, shadow_tmax)
+                                   : (PMODE == 3) ? any_hit_pairs_tlas(KD, PL, lane, lit, shadow_o, L, shadow_tmax, cyc)
+                                                  : any_hit<GEOM>(KD, lit, shadow_o, L, shadow_tmax, stk);
             if (lit && !in_shadow)
                 acc = acc + lit_now;
         }
         TS_ADD(13, t_sh);
 
         PT_MARK("E");
+        const KParams &KE = kparams(kp0);
         const unsigned long long t_pe = TS_NOW();
         // ---- [E] second half of the shading
         if (shaded) {
-            const Material mat = mats_lds ? load_material<true>(PL.mats, h_order) : load_material(K.materials, h.mesh);
+            const Material mat = mats_lds ? load_material<true>(PL.mats, h_order) : load_material(KE.materials, h.mesh);
             f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
             bool is_specular = false;
             if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular)) {
@@ -1699,7 +1849,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     rd = scatter_dir;
                     ray_spec = is_specular;
                     ++bounce;
-                    if (bounce >= K.max_depth)
+                    if (bounce >= KE.max_depth)
                         end_path = true;
                 }
             }
@@ -1721,34 +1871,35 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     }
 
     PT_MARK("Z");
+    const KParams &KZ = kparams(kp0);
     TS_ADD(14, t_kernel);
     cyc.flush(lane);
     if (inside) {
         const int x = px(), yl = pyl();
-        const size_t idx = (size_t)yl * K.width + x;
-        K.rng[idx] = rng.d;
-        K.rng[npix + idx] = rng.v0;
-        K.rng[2 * npix + idx] = rng.v1;
-        K.rng[3 * npix + idx] = rng.v2;
-        K.rng[4 * npix + idx] = rng.v3;
-        K.rng[5 * npix + idx] = rng.v4;
-        const f3 out = avg_color / (float)K.spp;
-        K.accum[idx * 3 + 0] = out.x;
-        K.accum[idx * 3 + 1] = out.y;
-        K.accum[idx * 3 + 2] = out.z;
+        const size_t idx = (size_t)yl * KZ.width + x, npix = KZ.rng_plane;
+        KZ.rng[idx] = rng.d;
+        KZ.rng[npix + idx] = rng.v0;
+        KZ.rng[2 * npix + idx] = rng.v1;
+        KZ.rng[3 * npix + idx] = rng.v2;
+        KZ.rng[4 * npix + idx] = rng.v3;
+        KZ.rng[5 * npix + idx] = rng.v4;
+        const f3 out = avg_color / (float)KZ.spp;
+        KZ.accum[idx * 3 + 0] = out.x;
+        KZ.accum[idx * 3 + 1] = out.y;
+        KZ.accum[idx * 3 + 2] = out.z;
         // (tonemap_kernel fused, below: RGB8, rows flipped within the tile (scene.cuh:2013-2015); skipped -- wave-uniform --
         // when a denoiser / bloom / up-scale stage follows and tonemaps its own result)
     }
-    if (K.rgb8) {
+    if (KZ.rgb8) {
         // A tile row is 8 pixels = 24 contiguous bytes of the bottom-up image.  Full tiles of a frame whose rows are
         // dword-aligned leave as six dwords per row: lane c < 6 of a row takes the (at most two) pixels its dword
         // spans out of their lanes' registers (ds_bpermute), instead of three byte stores per lane.
         const int x = px(), yl = pyl();
         unsigned char r8 = 0, g8 = 0, b8 = 0;
         if (inside)
-            tonemap_pixel(avg_color / (float)K.spp, r8, g8, b8);
-        const bool full_tile = (tx * 8 + 8 <= K.width) && (ty * 8 + 8 <= K.rows) && (K.width % 4 == 0) &&
-                               (((size_t)K.rgb8 & 3u) == 0u);
+            tonemap_pixel(avg_color / (float)KZ.spp, r8, g8, b8);
+        const bool full_tile = (tx * 8 + 8 <= KZ.width) && (ty * 8 + 8 <= KZ.rows) && (KZ.width % 4 == 0) &&
+                               (((size_t)KZ.rgb8 & 3u) == 0u);
         if (full_tile) {
             const uint32_t pix = (uint32_t)r8 | ((uint32_t)g8 << 8) | ((uint32_t)b8 << 16);
             const int c = lane & 7, first = (4 * c) / 3;                 // first pixel of dword c; byte offset in it: (4c) % 3
@@ -1756,17 +1907,17 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             const unsigned long long two = (unsigned long long)(uint32_t)__shfl((int)pix, src) |
                                            ((unsigned long long)(uint32_t)__shfl((int)pix, src1) << 24);
             if (c < 6) {
-                uint32_t *row = (uint32_t *)(K.rgb8 + ((size_t)(K.rows - 1 - yl) * K.width + (size_t)tx * 8) * 3);
+                uint32_t *row = (uint32_t *)(KZ.rgb8 + ((size_t)(KZ.rows - 1 - yl) * KZ.width + (size_t)tx * 8) * 3);
                 row[c] = (uint32_t)(two >> (8 * ((4 * c) % 3)));
             }
         } else if (inside) {
-            const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
-            K.rgb8[o + 0] = r8;
-            K.rgb8[o + 1] = g8;
-            K.rgb8[o + 2] = b8;
+            const size_t o = ((size_t)(KZ.rows - 1 - yl) * KZ.width + x) * 3;
+            KZ.rgb8[o + 0] = r8;
+            KZ.rgb8[o + 1] = g8;
+            KZ.rgb8[o + 2] = b8;
         }
     }
-    if (K.counters) {
+    if (KZ.counters) {
         if (LDS_COUNT) {
             wave_sync();
             const unsigned long long t = lds_count[0];
@@ -1775,13 +1926,13 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             n_zero = (uint32_t)lds_count[1];
         }
         const uint32_t a = n_ext, b = n_shadow,
-                       c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside)) * (uint32_t)K.spp;
+                       c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside)) * (uint32_t)KZ.spp;
         // one slot of four counters per workgroup, plain read-modify-write (only this workgroup touches
         // it within a launch; launches are ordered).  Three atomics per wave on three shared addresses
         // serialised at the L2 atomic unit: 97 K of them took 1.2 ms per 1080p frame -- hidden behind a
         // 2.7-ms trace, but the whole cost of a light frame (1 spp, 1 bounce: 1.19 ms -> 0.17 ms).
         if (lane == 0) {
-            unsigned long long *w = K.counters + (size_t)tile * COUNTER_WORDS;
+            unsigned long long *w = KZ.counters + (size_t)tile * COUNTER_WORDS;
             w[0] += (unsigned long long)a;
             w[1] += (unsigned long long)b;
             w[2] += (unsigned long long)c;

@@ -65,6 +65,7 @@ struct ptrt_ctx {
     bool rng_ready = false;
 
     // scene arena
+    float4 *d_nodes2 = nullptr; // two-level records derived from d_nodes (pt::expand_nodes_kernel), NODE2_F4 float4 per node
     float4 *d_mesh_recs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_tlas_nodes = nullptr,
            *d_materials = nullptr, *d_lights = nullptr;
     int2 *d_leaves = nullptr, *d_tlas_leaves = nullptr;
@@ -164,6 +165,7 @@ struct ptrt_ctx {
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
     int lds_pad = 0; // extra bytes of LDS per workgroup (A/B of the occupancy)
+    int pm1_wg = 0;  // PMODE 1, simple materials: tiles per workgroup (0 = two when the scene fits, else one; 1 / 2 force)
     int stage = 7; // PMODE 1, shading inputs staged in LDS: 0 none, else jitter table + blue noise, | 1 lights, | 2 materials
     int lds_nodes = 0; // option: PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels (measured slower: DESIGN.md 3.1)
     int n_nodes = 0;
@@ -457,6 +459,7 @@ void free_scene(ptrt_ctx *c) {
     drop_graphs(c); // captured launch sequences hold arena pointers
     dfree(c->d_mesh_recs);
     dfree(c->d_nodes);
+    dfree(c->d_nodes2);
     dfree(c->d_tris);
     dfree(c->d_tlas_nodes);
     dfree(c->d_leaves);
@@ -513,6 +516,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     pt::KParams K{};
     K.mesh_recs = c->d_mesh_recs;
     K.nodes = c->d_nodes;
+    K.nodes2 = c->d_nodes2;
     K.leaves = c->d_leaves;
     K.tris = c->d_tris;
     K.slot_face = c->d_slot_face;
@@ -607,7 +611,7 @@ size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
                256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES + 16;
     // staged heads (PMODE 1: and the mesh table), 16-bit pair entries, the rays' minima (whose second half holds the any-hit flags)
     const size_t common = (size_t)c->pair_meshes * (pmode == 1 ? 48 : 32) + (size_t)c->pair_meshes * 128 + 512;
-    return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16
+    return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16 + 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16; // (+ the ray totals)
 }
 // 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
@@ -758,6 +762,13 @@ void drop_graphs(ptrt_ctx *c) {
     c->graphs.clear();
 }
 
+// the two-level records follow the canonical nodes (after an upload, a refit, a rebuild)
+void enqueue_expand_nodes(ptrt_ctx *c, hipStream_t st) {
+    if (PT_TWO_LEVEL && c->n_nodes > 0 && c->d_nodes2)
+        hipLaunchKernelGGL(pt::expand_nodes_kernel, dim3((c->n_nodes * 3 + 255) / 256), dim3(256), 0, st, c->d_nodes, c->d_nodes2,
+                           c->n_nodes);
+}
+
 int enqueue_refit(ptrt_ctx *c, hipStream_t st) {
     const int B = 256;
     if (c->n_slots > 0)
@@ -787,6 +798,7 @@ int enqueue_refit(ptrt_ctx *c, hipStream_t st) {
     hipLaunchKernelGGL(pt::refit_top_levels_kernel, dim3(1), dim3(1024), 0, st, c->d_level_nodes, T, c->d_node_dst,
                        c->d_nodes, c->d_mesh_recs, c->d_tlas_leaves, c->d_tlas_mesh_ids, c->tlas_root_ref,
                        c->d_tlas_root_box);
+    enqueue_expand_nodes(c, st);
     HIP_TRY(c, hipGetLastError());
     return PTRT_OK;
 }
@@ -1363,6 +1375,11 @@ int ptrt_upload_geometry(ptrt_ctx *c, const ptrt_mesh_desc *meshes, int mesh_cou
     if (int rc = upload(c, c->d_nodes, R.nodes))
         return rc;
     c->n_nodes = (int)(R.nodes.size() / 4);
+    dfree(c->d_nodes2);
+    if (PT_TWO_LEVEL) { // (a build whose queue modes read two-level records: measured, no gain -- DESIGN.md 3.11)
+        HIP_TRY(c, hipMalloc((void **)&c->d_nodes2, (size_t)(c->n_nodes > 0 ? c->n_nodes : 1) * pt::NODE2_F4 * sizeof(float4)));
+        enqueue_expand_nodes(c, c->stream);
+    }
     if (int rc = upload(c, c->d_leaves, R.leaves))
         return rc;
     if (int rc = upload(c, c->d_tris, R.tris))
@@ -2002,27 +2019,54 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                            c->inst_pre_ok ? 1 : 0);
         HIP_TRY(c, hipGetLastError());
     }
-    // PMODE 1 stages its shading inputs behind the lists (KParams::lds_extra) while that keeps the workgroup within the
-    // LDS that the occupancy its kernel is built for leaves each wave (pt::lds_per_wave)
+    // PMODE 1 (pt::carve_pm1): the read-only copies are per workgroup, the lists per wave.  With the simple materials the
+    // kernel exists for one tile per workgroup at five waves per SIMD and for TWO tiles at six (option pm1_wg: 0 = the larger
+    // one if the scene fits its LDS budget, 1 / 2 force); the shading inputs are staged piece by piece while the workgroup
+    // stays within the budget of the occupancy its kernel is built for.
     size_t lds_main = lds + (size_t)c->lds_pad;
-    if (pmode == 1 && c->stage) { // (piece by piece, while they fit)
-        const size_t at = (lds + 15) & ~(size_t)15, budget = (size_t)pt::lds_per_wave(1, full);
-        size_t extra = pt::LDS_EXTRA_FIXED;
-        if (at + extra + (size_t)c->lds_pad <= budget) {
-            int flags = 4;
-            const size_t lights = (size_t)c->n_lights * 64, mats = (size_t)c->pair_meshes * 96;
-            if ((c->stage & 1) && c->n_lights > 0 && c->n_lights <= pt::LDS_LIGHTS && at + extra + lights + (size_t)c->lds_pad <= budget) {
-                flags |= 1;
-                extra += lights;
+    int pm1_wg = 1;
+    if (pmode == 1) {
+        const size_t shared0 = (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * (pt::PAIR_PAD * 16 + 16 + 32);
+        const size_t lights = (size_t)c->n_lights * 64, mats = (size_t)c->pair_meshes * 96;
+        auto layout = [&](int wg, size_t budget, pt::KParams &P, bool may_stage = true) -> size_t { // bytes of the workgroup, 0 if over budget
+            const size_t wave0 = 512 + (size_t)c->pair_meshes * 128 + 16;
+            size_t shared = (shared0 + 15) & ~(size_t)15;
+            int flags = 0;
+            if (shared + wg * wave0 + (size_t)c->lds_pad > budget)
+                return 0;
+            const size_t extra_at = shared;
+            size_t wave = wave0;
+            if (may_stage && c->stage && shared + 128 + wg * (wave0 + 512) + (size_t)c->lds_pad <= budget) {
+                flags = 4;
+                shared += 128;
+                wave += 512;
+                if ((c->stage & 1) && c->n_lights > 0 && c->n_lights <= pt::LDS_LIGHTS && shared + lights + wg * wave + (size_t)c->lds_pad <= budget) {
+                    flags |= 1;
+                    shared += lights;
+                }
+                if ((c->stage & 2) && c->pair_meshes <= 42 && shared + mats + wg * wave + (size_t)c->lds_pad <= budget) {
+                    flags |= 2;
+                    shared += mats;
+                }
             }
-            if ((c->stage & 2) && c->pair_meshes <= 42 && at + extra + mats + (size_t)c->lds_pad <= budget) {
-                flags |= 2;
-                extra += mats;
-            }
-            K.lds_extra = (int)at;
-            K.lds_flags = flags;
-            lds_main = at + extra + (size_t)c->lds_pad;
+            P.lds_extra = (int)extra_at;
+            P.lds_flags = flags;
+            P.lds_wave = (int)shared;
+            P.lds_wave_bytes = (int)wave;
+            return shared + wg * wave + (size_t)c->lds_pad;
+        };
+        size_t need = 0;
+        if (!full && c->pm1_wg != 1)
+            need = layout(2, (size_t)pt::lds_per_workgroup(1, false, 2), K);
+        if (need) {
+            pm1_wg = 2;
+        } else {
+            need = layout(1, (size_t)pt::lds_per_wave(1, full), K);
+            if (!need) // (over the budget of the kernel's occupancy: pair_mode admitted the scene, so it runs, with nothing staged)
+                need = layout(1, 64 * 1024, K, false);
         }
+        lds_main = need;
+        K.n_tiles = grid;
     }
     if (c->launches == 0 && getenv("PTRT_DEBUG_LDS"))
         fprintf(stderr, "ptrt: pmode %d, %d meshes in the leaf, %d triangle slots, stack %d, LDS %zu + %zu bytes per workgroup\n", pmode,
@@ -2038,7 +2082,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         if (int rc = run_wavefront(c, K, full, spp, max_depth))
             return rc;
         c->last_mode = 1;
-    } else if (pmode == 1)
+    } else if (pmode == 1 && pm1_wg == 2)
+        hipLaunchKernelGGL((pt::path_trace_kernel<0, false, 1, 2>), dim3((grid + 1) / 2), dim3(128), lds_main, c->stream, K);
+    else if (pmode == 1)
         launch_trace<0, 1>(c, K, full, grid, lds_main);
     else if (pmode == 4)
         launch_trace<1, 4>(c, K, full, grid, lds_main);
@@ -2574,6 +2620,11 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
             return fail(c, PTRT_E_INVALID, "lds_pad must be 0..32768");
         c->lds_pad = (int)value;
     }
+    else if (n == "pm1_wg") { // PMODE 1: one or two tiles per workgroup (0 = choose by the LDS budget; A/B, tests)
+        if (value < 0 || value > 2)
+            return fail(c, PTRT_E_INVALID, "pm1_wg must be 0..2");
+        c->pm1_wg = (int)value;
+    }
     else if (n == "stage") // PMODE 1: shading inputs staged in LDS (0 none; else jitter inputs, | 1 lights, | 2 materials; A/B, tests)
         c->stage = (int)(value & 7);
     else if (n == "pair_split") // PMODE 1: 0 = one lane per pair also in batches that do not fill the wave (A/B, tests)
@@ -2613,7 +2664,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

@@ -158,7 +158,7 @@ def _frames(P, build, opts, W=1920, H=1080, spp=4, depth=4, n_frames=2):
     out = []
     for _ in range(n_frames):
         rgb = s.render_to_host()
-        out.append(dict(rgb8=rgb, stats=s.stats(), **{k: s.read(b) for k, b in (
+        out.append(dict(rgb8=rgb, stats=s.stats(), render_mode=s.get_option("render_mode"), **{k: s.read(b) for k, b in (
             ("accum", P.BUF_ACCUM), ("normal", P.BUF_NORMAL), ("depth", P.BUF_DEPTH), ("object_id", P.BUF_OBJECT_ID),
             ("rng", P.BUF_RNG))}))
     s.close()
@@ -187,7 +187,8 @@ def test_full_size_traversal_variants_agree(P, scene):
     #  the async / wavefront kernels take single-leaf TLASes only and fall back to the same default there)
     # merged=0: separate closest-hit and any-hit phases (PMODE 2) instead of one traversal per iteration (PMODE 4)
     # lds_nodes=1: four tiles per workgroup sharing an LDS copy of the mesh heads and of the BLAS top levels
-    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1)):
+    # pm1_wg=1: one tile per workgroup where the default gives two tiles one LDS copy of a small scene (PMODE 1)
+    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=1)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):
             for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):
@@ -196,7 +197,8 @@ def test_full_size_traversal_variants_agree(P, scene):
                     av, bv = av.view(np.uint32), bv.view(np.uint32)
                 assert np.array_equal(av, bv), f"{scene} {opts} frame {f}: {k} differs in {(av != bv).sum()} words"
             # (the asynchronous-lane kernel walks every shadow ray; the others count the zero-valued light samples apart)
-            want = dict(a["stats"], shadow_rays_walked=a["stats"]["shadow_rays"]) if opts.get("async_lanes") else a["stats"]
+            # (render_mode 2: it really ran -- a scene with a real TLAS falls back to the default kernel)
+            want = dict(a["stats"], shadow_rays_walked=a["stats"]["shadow_rays"]) if b["render_mode"] == 2 else a["stats"]
             assert want == b["stats"], f"{scene} {opts} frame {f}"
             assert a["stats"]["shadow_rays_walked"] <= a["stats"]["shadow_rays"]
     assert ref[0]["accum"].any()

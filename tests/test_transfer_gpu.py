@@ -78,11 +78,13 @@ def test_update_pt_scene_then_commit_reaches_the_gpu_path(P, O, blue_noise, tmp_
     for k, f in enumerate(frames):
         if k > 0:
             P.scenes.transfer_step(s, water, cube, k)
+        fc = s.getFrameCount()  # (a commit restarts the accumulation: the frame index, and with it the jitter, begins again)
+        assert fc == 0
         rgb = s.render_to_host()
         accum = s.read(P.BUF_ACCUM)
         assert s.serialize() == f["scene"], f"step {k}: the probe's scene and the recipe's differ"
         assert np.array_equal(rgb.reshape(-1, 3), f["rgb8"]) and np.array_equal(bits(accum), bits(f["accum"])), f"step {k}"
-        c = O.render(s.flatten(), w, h, spp, depth, k, blue_noise, rng, threads=8)
+        c = O.render(s.flatten(), w, h, spp, depth, fc, blue_noise, rng, threads=8)
         assert np.array_equal(bits(c["accum"]), bits(f["accum"])), f"step {k}: the probe's frame differs from the oracle's"
         assert np.array_equal(O.tonemap(c["accum"], w, h, threads=4).reshape(-1, 3), f["rgb8"])
         assert np.array_equal(s.read(P.BUF_RNG), rng)
@@ -107,8 +109,9 @@ def test_policy_falls_back_when_the_topology_changes(P, O, blue_noise):
     rng = O.xorwow_init(P.DEFAULT_SEED, 0, w * h)
 
     def frame(k):
+        fc = s.getFrameCount()
         rgb = s.render_to_host()
-        c = O.render(s.flatten(), w, h, 1, 3, k, blue_noise, rng, threads=4)
+        c = O.render(s.flatten(), w, h, 1, 3, fc, blue_noise, rng, threads=4)
         assert np.array_equal(bits(s.read(P.BUF_ACCUM)), bits(c["accum"])), k
         assert np.array_equal(O.tonemap(c["accum"], w, h).reshape(-1), rgb.reshape(-1))
 

@@ -472,8 +472,10 @@ def main():
             tf_.render_to_device(target.data_ptr())
         tf_.sync()
         t0 = time.perf_counter()
+        farm_host = []
         for _ in range(args.steps):
             tf_.render_to_device(target.data_ptr())
+            farm_host.append(tf_.host_us)  # the calling thread's time inside the frame (parts enqueued on worker threads)
         tf_.sync()
         for d in range(ndev):
             torch.cuda.synchronize(d)
@@ -532,6 +534,7 @@ def main():
     if farm_ms is not None:
         out["config"]["farm_ms_per_frame"] = round(farm_ms, 4)
         out["config"]["farm"] = f"{args.farm} parts, {args.layout}, one process, transport {farm_transport}"
+        out["config"]["farm_host_us_per_frame"] = round(sorted(farm_host)[len(farm_host) // 2], 1)
     if present is not None:
         out["config"]["present_ms_per_frame"] = round(present, 4)
         out["config"]["present_slots"] = args.present

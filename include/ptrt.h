@@ -441,6 +441,17 @@ int ptrt_farm_bands(const ptrt_farm *farm);
 const char *ptrt_farm_transport(const ptrt_farm *farm);
 int ptrt_farm_render(ptrt_farm *farm, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device);
 int ptrt_farm_gather(ptrt_farm *farm, void *out_rgb8, int out_is_device);
+/* ABI 5.  The per-part host work of a frame runs on one worker thread per context (a ptrt_render costs 20-50 us of host
+ * time; eight in a row would be the same order as an eighth of a frame on the GPU):
+ *   ptrt_farm_parallel   fn(i, user) for every context i at once, each on its own thread (the caller's takes part 0); returns
+ *                        when all are back; fn must not throw.  ptrt_farm_render uses it for its ptrt_render calls, the
+ *                        C++ TileFarm for its Scene::render_to_device calls.
+ *   ptrt_farm_host_us    host time (us) of the caller's thread inside the last ptrt_farm_render
+ *   ptrt_farm_set_option "parallel" 0|1 (default 1), "spin_us" (a worker polls that long for the next frame before it
+ *                        sleeps; default 2000) */
+int ptrt_farm_parallel(ptrt_farm *farm, void (*fn)(int part, void *user), void *user);
+double ptrt_farm_host_us(const ptrt_farm *farm);
+int ptrt_farm_set_option(ptrt_farm *farm, const char *name, long long value);
 int ptrt_farm_sync(ptrt_farm *farm);
 void ptrt_farm_destroy(ptrt_farm *farm);
 
@@ -459,6 +470,8 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         blocks the host (a hipEventSynchronize on frame 9, once per scene and setting); set merged to 0 or 1
  *                         before the first frame to opt out.  Never taken while the stream is being captured into a hipGraph.
  *   stage 0..7            PMODE 1: shading inputs kept in LDS (0 none; else jitter inputs, |1 light records, |2 material records)
+ *   tlas_rounds 0|1       real TLAS: shadow rays take one TLAS leaf per fill of the pair list (what > 1024 meshes use) instead of all
+ *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)
  *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9
  *   denoiser_active, motion_vectors, use_graphs 0|1 */

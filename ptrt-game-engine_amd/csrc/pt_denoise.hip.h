@@ -26,6 +26,7 @@
 // to oracle/denoiser_oracle.cpp.  The reference runs temporal_accumulation in place (a race);
 // here every read sees the pre-kernel image, as in the oracle.
 #pragma once
+#include <type_traits>
 #include "pt_device.hip.h"
 
 namespace pt {
@@ -410,33 +411,46 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
         const float inv_sl2 = 1.0f / (2.0f * asl * asl + 1e-6f);
         f3 sum = mk3(0.0f);
         float sum_var = 0.0f, total_w = 0.0f;
+        // The reference's chain of early `continue`s (denoiser.cuh:686-721) as ONE predicate per tap: every operand of a tap is
+        // loaded unconditionally (an entry outside the image holds whatever the LDS held: its values take part in comparisons
+        // whose results the first conjunct discards), so the LDS reads of a tap do not wait for its branches.
+        // Relative-depth test `dd / max_d > edt`: q~ = dd * v_rcp_f32(max_d) is within 2^-22 of the quotient, the correctly
+        // rounded quotient within 2^-24; outside edt (1 +- 2^-20) both sides of the comparison agree, and the division itself
+        // runs only for a wave in which some tap lands in that band (or compares NaNs, or has a depth beyond 2^120, whose
+        // reciprocal is not v_rcp_f32's business).
+        // (Measured and dropped: the tap's contribution as selects too -- straight-line code over the 25 taps, all reads in
+        // flight -- 125-131 us per pass against 87: the exponential of every rejected tap costs more than the branch saves.)
+        const float e_lo = min_(edt * (1.0f - 0x1p-20f), edt * (1.0f + 0x1p-20f)), e_hi = max_(edt * (1.0f - 0x1p-20f), edt * (1.0f + 0x1p-20f));
+#pragma unroll
         for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
             for (int dx = -2; dx <= 2; ++dx) {
                 const int ne = ce + dy * span + dx * step; // (x + dx*step, y + dy*step)
                 const int nobj = s_o[ne];
-                if (nobj == AT_OUTSIDE) // nx < 0 || nx >= W || ny < 0 || ny >= H
-                    continue;
-                if (uo && cobj != nobj && cobj >= 0 && nobj >= 0)
-                    continue;
                 const float4 ng = s_g[ne];
+                const float4 nc4 = s_c[ne];
+                bool ok = nobj != AT_OUTSIDE; // nx < 0 || nx >= W || ny < 0 || ny >= H
+                ok = ok && !(uo && cobj != nobj && cobj >= 0 && nobj >= 0);
                 const float max_d = max_(cd, ng.w);
                 const float dd = __builtin_fabsf(cd - ng.w);
-                if (max_d > 1e-6f && dd / max_d > edt)
-                    continue;
+                const float qa = dd * __builtin_amdgcn_rcpf(max_d);
+                bool far = qa > e_hi;
+                const bool unsure = ok && max_d > 1e-6f && ((!(qa > e_hi) && !(qa < e_lo)) || !(max_d < 0x1p120f));
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(unsure) != 0ull, 0))
+                    far = unsure ? (dd / max_d > edt) : far;
+                ok = ok && !(max_d > 1e-6f && far);
                 const f3 nn = xyz(ng);
-                if (dot(cn, nn) < ent)
-                    continue;
-                if (is_sky(ng.w, nn, sky))
-                    continue;
-                const float4 nc4 = s_c[ne];
-                const f3 nc = xyz(nc4);
-                const float ld = __builtin_fabsf(clum - luminance(nc));
-                const float wl = det_exp(-ld * ld * inv_sl2);
-                // atrous_kernel[k] = (a*b)/256 with a,b in {1,4,6}: products and the /256 are exact in fp32
-                const float weight = (KW[dy + 2] * KW[dx + 2] / 256.0f) * wl;
-                sum = sum + nc * weight;
-                sum_var += nc4.w * weight;
-                total_w += weight;
+                ok = ok && !(dot(cn, nn) < ent) && !is_sky(ng.w, nn, sky);
+                if (ok) {
+                    const f3 nc = xyz(nc4);
+                    const float ld = __builtin_fabsf(clum - luminance(nc));
+                    const float wl = det_exp(-ld * ld * inv_sl2);
+                    // atrous_kernel[k] = (a*b)/256 with a,b in {1,4,6}: products and the /256 are exact in fp32
+                    const float weight = (KW[dy + 2] * KW[dx + 2] / 256.0f) * wl;
+                    sum = sum + nc * weight;
+                    sum_var += nc4.w * weight;
+                    total_w += weight;
+                }
             }
         if (!(total_w < 1e-6f)) {
             const float inv_w = 1.0f / total_w;

@@ -208,12 +208,11 @@ PT_DEV float det_sin(float x) {
     return s;
 }
 PT_DEV float det_exp(float x) {
-    if (x != x)
-        return x;
-    if (x > 88.72283f)
-        return __uint_as_float(0x7f800000u);
-    if (x < -104.0f)
-        return 0.0f;
+    // (the three special cases are selects AFTER the core, not branches around it: for an argument outside the range the core
+    // computes garbage that is then replaced -- same bits as the early returns of oracle/detmath.h.  Measured against the
+    // branches: temporal_kernel 114 -> 103 us, an a-trous pass 88 -> 90 us, path tracing unchanged)
+    const float x_in = x;
+    x = (x >= -104.0f && x <= 88.72283f) ? x : 0.0f;
     const float kf = __builtin_rintf(x * 0x1.715476p+0f);
     float r = fma_(-kf, 0x1.62e4p-1f, x);
     r = fma_(-kf, 0x1.7f7d1cp-20f, r);
@@ -229,7 +228,10 @@ PT_DEV float det_exp(float x) {
     const int k2 = k - k1;
     const float s1 = __uint_as_float((uint32_t)(k1 + 127) << 23);
     const float s2 = __uint_as_float((uint32_t)(k2 + 127) << 23);
-    return (p * s1) * s2;
+    float e = (p * s1) * s2;
+    e = (x_in < -104.0f) ? 0.0f : e;
+    e = (x_in > 88.72283f) ? __uint_as_float(0x7f800000u) : e;
+    return (x_in != x_in) ? x_in : e;
 }
 PT_DEV float det_log(float x) {
     if (x != x)
@@ -880,17 +882,33 @@ PT_DEV bool material_scatter(const Surface &hit, const Material &mat, f3 ray_dir
     const float u = rng_uniform(rng);
     const bool pick_coat = FULL && (u < P_coat);
     const bool pick_spec = !pick_coat && (u < P_coat + P_opaque_spec);
-    if (pick_coat || pick_spec) {
-        const float r = pick_coat ? clearcoatRough : rough;
-        const f3 H = importance_sample_ggx(rng, N, r);
-        scattered_dir = reflectVec(-V, H);
-        is_specular_bounce = (r < 0.1f);
-    } else if (P_opaque_diff > 1e-6f) {
-        const f3 hemi = sample_cosine_hemisphere(rng);
-        scattered_dir = to_world(hemi, N);
-        is_specular_bounce = false;
-    } else {
+    const bool ggx = pick_coat || pick_spec;
+    if (!ggx && !(P_opaque_diff > 1e-6f))
         return false;
+    {
+        // importance_sample_ggx (sampling.cuh:187-208) for the lanes that picked a specular lobe and sample_cosine_hemisphere
+        // (:141-164) for the others in ONE pass: both draw two uniforms, take the sine and cosine of 2 pi times one of them,
+        // two square roots, and turn a local vector into N's frame -- a wave that holds both kinds (most do: the lobe is a
+        // per-lane draw) used to run the two functions one after the other.  Every lane performs exactly the operations of
+        // its own function, on its own operands.
+        const float r = pick_coat ? clearcoatRough : rough;
+        const float a = r * r, a2 = a * a;
+        const float u1 = rng_uniform(rng);
+        const float u2r = rng_uniform(rng);
+        const float u2 = ggx ? min_(u2r, 0.9999999f) : u2r;
+        float sp, cp;
+        det_sincos(TWO_PI_F * (ggx ? u1 : u2), sp, cp);
+        // ggx: s1 = cos(theta) = sqrt((1 - u2) / (1 + (a2 - 1) u2)), s2 = sin(theta) = sqrt(max(0, 1 - s1 s1));
+        // cosine: s1 = radius = sqrt(u1), s2 = z = sqrt(max(0, 1 - u1))
+        const float s1 = sqrt_ieee(ggx ? (1.0f - u2) / (1.0f + (a2 - 1.0f) * u2) : u1);
+        const float s2 = sqrt_ieee(max_(0.0f, 1.0f - (ggx ? s1 * s1 : u1)));
+        const float rad = ggx ? s2 : s1, up = ggx ? s1 : s2;
+        const f3 w = to_world(mk3(rad * cp, rad * sp, up), N);
+        const f3 refl = reflectVec(-V, w);
+        scattered_dir.x = ggx ? refl.x : w.x;
+        scattered_dir.y = ggx ? refl.y : w.y;
+        scattered_dir.z = ggx ? refl.z : w.z;
+        is_specular_bounce = ggx && (r < 0.1f);
     }
     scattered_dir = normalize(scattered_dir);
     const float NdotL = max_(dot(N, scattered_dir), 0.0f);

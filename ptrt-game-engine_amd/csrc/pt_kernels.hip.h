@@ -77,6 +77,7 @@ struct KParams {
     int pair_max_leaf;  // largest leaf
     int tlas_max_leaf;  // PMODE 3: most meshes in one TLAS leaf
     int tlas_depth;     // PMODE 3: TLAS stack entries per lane
+    int tlas_any_rounds; // PMODE 3 shadow rays: 1 = one TLAS leaf per ray and fill (more than 1024 meshes, or option tlas_rounds)
     int pair_split;     // PMODE 1: a batch that does not fill the wave may give each pair several lanes
     int steal;          // PMODE 2 any-hit: 0 off; n > 0: idle lanes steal subtrees, node loop yields every n steps
     int leaf_min;       // PMODE 2: lanes waiting at a leaf that end the node loop (64 = all of them)

@@ -315,7 +315,7 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
 // ray of a pair in the mesh's space (tri_test needs origin and direction only), from the world ray -- fetched from the
 // owner lane's registers by ds_bpermute: no ray planes in LDS
 // (`GEN`: mt.w is a TLAS index and the rows come from the leaf-order copy; else it is a mesh id)
-template <bool GEN = false> PT_DEV void pair_ray_from(const KParams &K, const int4 mt, f3 &o, f3 &d, float &dirScale) {
+template <int GEN = 0> PT_DEV void pair_ray_from(const KParams &K, const int4 mt, f3 &o, f3 &d, float &dirScale) {
     dirScale = 1.0f;
     if (mt.z & 1) {
         const float4 *rec = GEN ? (K.tlas_heads + mt.w * TLAS_HEAD_F4) : (K.mesh_recs + mt.w * MESH_REC_F4);
@@ -473,12 +473,12 @@ PT_DEV bool any_hit_pairs(const KParams &K, const PairLds &L, int lane, bool ali
 // traversal state.  Every pair is still traversed exactly as before, so the bits cannot change.
 // mesh of a pair entry.  GEN = false: `order` indexes the single TLAS leaf (the staged heads).  GEN = true (general TLAS,
 // PMODE 3): `order` indexes the TLAS leaf the RAY is currently at (L.leafx[r]), the head comes from the mesh records.
-template <bool GEN> PT_DEV int4 pair_mesh(const KParams &K, const PairLds &L, int r, int order) {
+// GEN 0: `order` indexes the single TLAS leaf; 1: leaf slot of this fill | index in that leaf << 2; 2: the TLAS index itself
+template <int GEN> PT_DEV int4 pair_mesh(const KParams &K, const PairLds &L, int r, int order) {
     if (!GEN)
         return staged_mesh_entry(L, order);
     // (root reference and flags from the leaf-order copy of the heads; the mesh id only matters for an instance's matrices)
-    // (order = leaf slot of this fill | index in that leaf << 2)
-    const int j = L.leafx[(order & (TLAS_SLOTS - 1)) * 64 + r] + (order >> 2);
+    const int j = GEN == 2 ? order : L.leafx[(order & (TLAS_SLOTS - 1)) * 64 + r] + (order >> 2);
     const int root = __float_as_int(K.tlas_heads[TLAS_HEAD_F4 * j].w), flags = __float_as_int(K.tlas_heads[TLAS_HEAD_F4 * j + 1].w);
     return make_int4(root, 0, flags, j);
 }
@@ -575,7 +575,7 @@ PT_DEV bool descend2_any(const float4 *__restrict__ nodes2, LdsStack stk, int &s
 }
 
 // drains the pair queue [0, P): afterwards L.best[r] = min over ray r's pairs of {t bits, order << 24 | slot}
-template <bool GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
+template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
     LdsStack stk{L.stack + lane};
     int next = 0;
     bool busy = false, active = false, xf = false;
@@ -807,7 +807,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
 // Any hit, same queue.  A pair whose ray is already known to be occluded is dropped at refill (the
 // answer is an OR over the ray's pairs).
 // drains the pair queue [0, P): afterwards L.occ[r] != 0 for every ray r one of whose pairs found a hit
-template <bool GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
+template <int GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
     LdsStack stk{L.stack + lane};
     const float *tmaxv = (const float *)L.best;
     int next = 0;
@@ -1035,9 +1035,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
 #endif
 // Root-box tests of every lane's NEXT leaf (`slot`-th leaf of this fill) -> pair entries lane | slot << 6 | index << 8
 // appended at `base`; returns the new length of the list.
-template <bool ANY>
-PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, bool has, int2 lf, const RayO &w, float tMax, int slot,
-                               int base) {
+template <bool ANY> PT_DEV uint32_t root_masks(const KParams &K, int lane, bool has, int2 lf, const RayO &w, float tMax) {
     // Pass 1, lock-step over the leaf's entries: ONE world-space slab test per entry.  For an untransformed mesh it is the
     // reference's root-box test.  For an instance it is a conservative pre-test: its first-pass box (gather_tlas_heads_
     // kernel), grown by inst_c2 * |o|_1 for this ray, contains every ray the reference's local-space test can accept, so a
@@ -1083,8 +1081,11 @@ PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, boo
                 mask |= 1u << i;
         }
     }
-    // the k-th hit of every lane, k = 0, 1, ...: ballot / prefix-sum compaction into the pair list (a leaf holds at
-    // most 17 meshes of which a ray's root tests pass one or two)
+    return mask;
+}
+// the k-th hit of every lane, k = 0, 1, ...: ballot / prefix-sum compaction into the pair list (a leaf holds at most 17
+// meshes of which a ray's root tests pass one or two); entry = lane | code(i) << 6 for hit i of the lane's leaf
+template <class Code> PT_DEV int append_pairs(const PairLds &L, int lane, uint32_t mask, int base, Code code) {
     for (;;) {
         const bool more = mask != 0u;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(more);
@@ -1093,11 +1094,17 @@ PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, boo
         if (more) {
             const int i = __builtin_ctz(mask);
             mask &= mask - 1u;
-            ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)slot << 6) | ((uint32_t)i << 8));
+            ((uint16_t *)L.pairs)[base + lane_prefix(bal)] = (uint16_t)((uint32_t)lane | ((uint32_t)code(i) << 6));
         }
         base += __builtin_popcountll(bal);
     }
     return base;
+}
+template <bool ANY>
+PT_DEV int build_pairs_general(const KParams &K, const PairLds &L, int lane, bool has, int2 lf, const RayO &w, float tMax, int slot,
+                               int base) {
+    const uint32_t mask = root_masks<ANY>(K, lane, has, lf, w, tMax);
+    return append_pairs(L, lane, mask, base, [slot](int i) { return slot | (i << 2); });
 }
 
 // One fill: up to TLAS_SLOTS times every lane walks the TLAS to its next leaf (near child first, culling with the closest
@@ -1228,9 +1235,9 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
     return best;
 }
 
-// Shadow rays: the same fills with the any-hit walk (bvh_any_hit_tlas, intersection.cuh:481-524).  Nothing to replay:
-// the answer is an OR over every leaf the walk reaches, and a ray seen blocked stops walking.
-PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax, CycleAcc &cyc) {
+// One leaf per ray and fill (the pair entry names the leaf slot and the index in it): what scenes with more than 1024 meshes
+// use, whose TLAS indices do not fit the 16-bit pair entries of the multi-leaf fills below.
+PT_DEV bool any_hit_pairs_tlas_rounds(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax, CycleAcc &cyc) {
     const RayO w = make_ray(o, d);
     float tE;
     bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, tMax, tE);
@@ -1296,7 +1303,7 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
             break;
         wave_sync();
         const unsigned long long t_q = TS_NOW();
-        run_any_queue<true>(K, L, lane, base, o, d);
+        run_any_queue<1>(K, L, lane, base, o, d);
         wave_sync();
         TS_ADD(8, t_q);
 #ifdef PT_TRAV_STATS
@@ -1304,6 +1311,113 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
 #endif
         if (L.occ[lane] != 0u)
             t_active = need_pop = false; // blocked: nothing more to look for
+        wave_sync();
+    }
+    return alive && (L.occ[lane] != 0u);
+}
+
+// Shadow rays: the any-hit walk (bvh_any_hit_tlas, intersection.cuh:481-524).  The answer is an OR over every leaf the walk
+// reaches, in any order and with nothing to cull by, so a fill does not stop at one leaf per ray: every lane keeps walking
+// the TLAS, leaf after leaf, and the wave keeps appending (ray, mesh) pairs -- the entry carries the TLAS index itself, so
+// no per-slot bookkeeping -- until no lane has a leaf left or the list cannot take the next leaf's hits; THEN the queue
+// runs, once, over all of them (one leaf per round was 1.5 pairs per queue run on the 136-mesh scene: 2.4 M runs per frame,
+// 41 % of a wave's life).  A leaf's hits are never split between fills (they are counted before they are appended); a
+// ray seen blocked drops its remaining pairs at refill and stops walking at the next fill.
+PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax, CycleAcc &cyc) {
+    if (K.tlas_any_rounds)
+        return any_hit_pairs_tlas_rounds(K, L, lane, alive, o, d, tMax, cyc);
+    const RayO w = make_ray(o, d);
+    float tE;
+    bool t_active = alive && slab(tlas_bmin(K), tlas_bmax(K), w, tMax, tE);
+    ((float *)L.best)[lane] = tMax;
+    L.occ[lane] = 0u;
+    int tcur = K.tlas_root_ref, tsp = 0;
+    bool need_pop = false;
+    auto pop_t = [&]() {
+        t_active = false;
+        if (tsp > 0) {
+            --tsp;
+            tcur = (int)L.tstack[tsp * 64 + lane].x;
+            t_active = true;
+        }
+    };
+    const int cap = K.tlas_max_leaf * 64 + TLAS_FILL_TARGET; // entries of the pair list (carve_pair_lds)
+    uint32_t held = 0u; // a leaf's hits that did not fit the previous fill
+    int held_first = 0;
+    bool holding = false; // (wave-uniform)
+    wave_sync();
+    for (;;) {
+        int base = 0;
+        for (;;) {
+            uint32_t mask = held;
+            int first = held_first;
+            if (!holding) {
+                int2 lf = make_int2(0, 0);
+                bool has = false;
+                const unsigned long long t_walk = TS_NOW();
+                if (need_pop)
+                    pop_t();
+                while (t_active && !has) {
+                    if (tcur >= 0) {
+                        const float4 n0 = K.tlas_nodes[tcur * 4 + 0], n1 = K.tlas_nodes[tcur * 4 + 1], n2 = K.tlas_nodes[tcur * 4 + 2],
+                                     n3 = K.tlas_nodes[tcur * 4 + 3];
+                        float tL, tR;
+                        const bool hL = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w, tMax, tL);
+                        const bool hR = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w, tMax, tR);
+                        const int Lr = __float_as_int(n3.x), Rr = __float_as_int(n3.y);
+                        if (hL && hR) {
+                            L.tstack[tsp * 64 + lane] = make_uint2((uint32_t)Rr, 0u);
+                            ++tsp;
+                            tcur = Lr;
+                        } else if (hL || hR) {
+                            tcur = hL ? Lr : Rr;
+                        } else {
+                            pop_t();
+                        }
+                    } else {
+                        lf = K.tlas_leaves[~tcur];
+                        has = true;
+                    }
+                }
+                need_pop = has;
+                TS_ADD(9, t_walk);
+                if (!__builtin_amdgcn_ballot_w64(has))
+                    break;
+                const unsigned long long t_b = TS_NOW();
+                mask = root_masks<true>(K, lane, has, lf, w, tMax);
+                first = lf.x;
+                TS_ADD(10, t_b);
+            }
+            // hits of this leaf over the wave (a lane has at most 32): bit planes of the lanes' counts
+            int total = 0;
+            const int cnt = __builtin_popcount(mask);
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((cnt >> b) & 1)) << b;
+            if (base + total > cap) { // (never with base == 0: one leaf's hits always fit)
+                held = mask;
+                held_first = first;
+                holding = true;
+                break;
+            }
+            holding = false;
+            held = 0u;
+            base = append_pairs(L, lane, mask, base, [first](int i) { return first + i; });
+        }
+        if (base == 0)
+            break; // (no lane found another leaf, and nothing is held back)
+        wave_sync();
+        const unsigned long long t_q = TS_NOW();
+        run_any_queue<2>(K, L, lane, base, o, d);
+        wave_sync();
+        TS_ADD(8, t_q);
+#ifdef PT_TRAV_STATS
+        cyc.c[7] += 1; // fills (any)
+#endif
+        if (L.occ[lane] != 0u) {
+            t_active = need_pop = false; // blocked: nothing more to look for
+            held = 0u;
+        }
         wave_sync();
     }
     return alive && (L.occ[lane] != 0u);

@@ -165,7 +165,11 @@ struct ptrt_ctx {
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
     int lds_pad = 0; // extra bytes of LDS per workgroup (A/B of the occupancy)
-    int pm1_wg = 0;  // PMODE 1, simple materials: tiles per workgroup (0 = two when the scene fits, else one; 1 / 2 force)
+    // PMODE 1, simple materials: tiles per workgroup.  1 (default): five waves per SIMD.  2: two tiles share the LDS copies, six
+    // waves per SIMD on 80 VGPRs -- measured on Cornell 1080p: 1.875 vs 1.877 ms, the 112 B per lane it spills eat what 24
+    // instead of 20 waves per CU bring.  0: two when the scene fits that budget.
+    int pm1_wg = 1;
+    int tlas_rounds = 0; // option (A/B, tests): PMODE 3 shadow rays take one TLAS leaf per fill, as scenes with > 1024 meshes do
     int stage = 7; // PMODE 1, shading inputs staged in LDS: 0 none, else jitter table + blue noise, | 1 lights, | 2 materials
     int lds_nodes = 0; // option: PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels (measured slower: DESIGN.md 3.1)
     int n_nodes = 0;
@@ -538,6 +542,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.pair_max_leaf = c->pair_max_leaf;
     K.tlas_max_leaf = c->tlas_max_leaf;
     K.tlas_depth = c->tlas_depth < 1 ? 1 : c->tlas_depth;
+    K.tlas_any_rounds = (c->n_meshes > 1024 || c->tlas_rounds) ? 1 : 0; // (TLAS indices beyond 10 bits do not fit a 16-bit pair entry)
     K.pair_split = (c->pair_split && !c->any_transform) ? 1 : 0;
     K.fetch_min = c->fetch_min > 0 ? c->fetch_min : 64; // 0 = refill only when the whole wave is idle: batches of 64
     K.pair_cap = merged_pair_cap(c);
@@ -1966,7 +1971,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     c->last_merged_possible = merged_possible;
     c->merged_eff = c->merged > 0 ? 1 : 0;
     bool capturing = false; // (a caller recording this stream into a hipGraph: no host wait, no choice -- the default shape)
-    {
+    if (c->merged < 0 && merged_possible && c->tune_choice < 0) { // (asked only while the choice is open: a driver call per frame otherwise)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess)
             capturing = cs != hipStreamCaptureStatusNone;
@@ -2620,6 +2625,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
             return fail(c, PTRT_E_INVALID, "lds_pad must be 0..32768");
         c->lds_pad = (int)value;
     }
+    else if (n == "tlas_rounds") // PMODE 3 shadow rays: one TLAS leaf per ray and fill instead of all of them (A/B, tests)
+        c->tlas_rounds = value ? 1 : 0;
     else if (n == "pm1_wg") { // PMODE 1: one or two tiles per workgroup (0 = choose by the LDS budget; A/B, tests)
         if (value < 0 || value > 2)
             return fail(c, PTRT_E_INVALID, "pm1_wg must be 0..2");
@@ -2664,7 +2671,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

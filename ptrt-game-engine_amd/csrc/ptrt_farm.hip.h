@@ -21,7 +21,66 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
+
+// One worker thread per context: a frame's parts are enqueued in parallel (a ptrt_render costs 20-50 us of host time; eight
+// of them in a row would be the same order as an eighth of a frame on the GPU).  A worker spins for `spin_us` after its last
+// job before it sleeps on its condition variable, so a render loop finds it awake (no futex round trip per frame) and an
+// idle application costs nothing.
+struct FarmWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<unsigned> posted{0}, done{0};
+    std::atomic<bool> quit{false};
+    void (*fn)(int, void *) = nullptr;
+    void *user = nullptr;
+    int index = 0;
+    std::atomic<int> spin_us{2000};
+    void run() {
+        unsigned seen = 0;
+        for (;;) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (posted.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_relaxed)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us.load(std::memory_order_relaxed))) {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(); });
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            if (quit.load())
+                return;
+            seen = posted.load(std::memory_order_acquire);
+            fn(index, user);
+            done.store(seen, std::memory_order_release);
+        }
+    }
+    void post(void (*f)(int, void *), void *u) {
+        fn = f;
+        user = u;
+        {
+            std::lock_guard<std::mutex> lk(m); // (pairs with the wait above: no lost wake-up)
+            posted.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_one();
+    }
+    void wait() const {
+        const unsigned want = posted.load(std::memory_order_relaxed);
+        while (done.load(std::memory_order_acquire) != want)
+            __builtin_ia32_pause();
+    }
+};
+
 struct ptrt_farm {
+    std::vector<std::unique_ptr<FarmWorker>> workers; // one per context, started on first use
+    double host_us = 0.0;                           // host time inside the last ptrt_farm_render / ptrt_farm_parallel + gather
+    std::vector<int> part_rc;
+    std::vector<std::string> part_err;
     std::vector<ptrt_ctx *> band;
     std::vector<hipEvent_t> rendered, taken; // per context: image complete / image copied out
     std::vector<unsigned char *> staging;    // per context on another device: where its image is received
@@ -32,6 +91,7 @@ struct ptrt_farm {
     hipStream_t stream = nullptr;            // presenting device: receives, copies
     unsigned char *d_frame = nullptr;        // assembled frame when the caller's target is host memory
     bool primed = false;
+    int parallel = 1, spin_us = 2000;
     std::string transport = "device-copy";
 };
 
@@ -79,7 +139,21 @@ bool farm_live(ptrt_farm *f) {
     return f && g_farms.count(f);
 }
 
+void farm_stop_workers(ptrt_farm *f) {
+    for (auto &w : f->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->quit.store(true);
+        }
+        w->cv.notify_one();
+        if (w->th.joinable())
+            w->th.join();
+    }
+    f->workers.clear();
+}
+
 void farm_free(ptrt_farm *f) {
+    farm_stop_workers(f);
     // nothing of the last frame may still be in flight when the communicators go: the receives and copies on the farm's
     // stream, the sends on the contexts' streams
     if (f->stream) {
@@ -307,14 +381,83 @@ int ptrt_farm_gather(ptrt_farm *f, void *out_rgb8, int out_is_device) {
     return PTRT_OK;
 }
 
-// One frame: every context renders its rows (asynchronously, each on its device), then the gather.
+// fn(i, user) for every context i of the farm, each on its own worker thread, all at once; returns when all are back.
+// What a frame's per-part host work goes through: ptrt_farm_render's ptrt_render calls, and TileFarm::frame's
+// Scene::render_to_device calls (host/ptrt/farm.hpp).  fn must not throw.  parallel = 0 (ptrt_farm_set_option): in a row.
+int ptrt_farm_parallel(ptrt_farm *f, void (*fn)(int, void *), void *user) {
+    if (!farm_live(f) || !fn)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_parallel: bad argument");
+    const int n = (int)f->band.size();
+    if (!f->parallel || n == 1) {
+        for (int i = 0; i < n; ++i)
+            fn(i, user);
+        return PTRT_OK;
+    }
+    if (f->workers.empty())
+        for (int i = 0; i < n; ++i) {
+            f->workers.emplace_back(new FarmWorker);
+            FarmWorker *w = f->workers.back().get();
+            w->index = i;
+            w->spin_us.store(f->spin_us);
+            w->th = std::thread([w] { w->run(); });
+        }
+    for (int i = 1; i < n; ++i)
+        f->workers[(size_t)i]->post(fn, user);
+    fn(0, user); // (the caller's thread takes the first part)
+    for (int i = 1; i < n; ++i)
+        f->workers[(size_t)i]->wait();
+    return PTRT_OK;
+}
+
+// One frame: every context renders its rows (asynchronously, each on its device, enqueued in parallel), then the gather.
 int ptrt_farm_render(ptrt_farm *f, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
     if (!farm_live(f))
         return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_render: bad farm");
-    for (ptrt_ctx *c : f->band)
-        if (int rc = ptrt_render(c, frame_index, spp, max_depth, nullptr, 0))
-            return rc;
-    return ptrt_farm_gather(f, out_rgb8, out_is_device);
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Job {
+        ptrt_farm *f;
+        int frame, spp, depth;
+    } job{f, frame_index, spp, max_depth};
+    f->part_rc.assign(f->band.size(), PTRT_OK);
+    f->part_err.assign(f->band.size(), std::string());
+    const int prc = ptrt_farm_parallel(f, [](int i, void *u) {
+        Job *j = static_cast<Job *>(u);
+        ptrt_ctx *c = j->f->band[(size_t)i];
+        const int rc = ptrt_render(c, j->frame, j->spp, j->depth, nullptr, 0);
+        j->f->part_rc[(size_t)i] = rc;
+        if (rc != PTRT_OK)
+            j->f->part_err[(size_t)i] = ptrt_last_error(c); // (the error text is per thread: carried back to the caller's)
+    }, &job);
+    if (prc != PTRT_OK)
+        return prc;
+    for (size_t i = 0; i < f->band.size(); ++i)
+        if (f->part_rc[i] != PTRT_OK)
+            return fail(nullptr, f->part_rc[i], "ptrt_farm_render: part %zu: %s", i, f->part_err[i].c_str());
+    const int rc = ptrt_farm_gather(f, out_rgb8, out_is_device);
+    f->host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+// host time (us) the caller's thread spent inside the last ptrt_farm_render (enqueue of every part + the gather's calls)
+double ptrt_farm_host_us(const ptrt_farm *f) { return farm_live(const_cast<ptrt_farm *>(f)) ? f->host_us : -1.0; }
+
+// parallel 0|1 (default 1): enqueue the parts from one worker thread per context, or in a row from the caller's thread;
+// spin_us: how long a worker polls for the next frame before it sleeps (default 2000)
+int ptrt_farm_set_option(ptrt_farm *f, const char *name, long long value) {
+    if (!farm_live(f) || !name)
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_set_option: bad argument");
+    const std::string n(name);
+    if (n == "parallel")
+        f->parallel = value ? 1 : 0;
+    else if (n == "spin_us") {
+        if (value < 0 || value > 1000000)
+            return fail(nullptr, PTRT_E_INVALID, "spin_us must be 0..1000000");
+        f->spin_us = (int)value;
+        for (auto &w : f->workers)
+            w->spin_us.store((int)value);
+    } else
+        return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_set_option: unknown option '%s'", name);
+    return PTRT_OK;
 }
 
 // waits until the last gathered frame is complete on the presenting device

@@ -427,6 +427,8 @@ int hs_farm_render(void *f, unsigned char *pixels, int is_device) {
     HS_TRY(is_device ? static_cast<TileFarm *>(f)->render_to_device(pixels) : static_cast<TileFarm *>(f)->render_to_host(pixels));
     return 0;
 }
+double hs_farm_host_us(void *f) { return static_cast<TileFarm *>(f)->hostMicroseconds(); }
+int hs_farm_set_parallel(void *f, int on) { HS_TRY(static_cast<TileFarm *>(f)->setParallel(on != 0)); return 0; }
 int hs_farm_sync(void *f) { HS_TRY(static_cast<TileFarm *>(f)->sync()); return 0; }
 void hs_farm_destroy(void *f) { delete static_cast<TileFarm *>(f); }
 

@@ -13,8 +13,10 @@
 #pragma once
 #include "scene.hpp"
 
+#include <chrono>
 #include <functional>
 #include <memory>
+#include <string>
 #include <vector>
 
 class TileFarm {
@@ -78,9 +80,31 @@ class TileFarm {
         if (rc != PTRT_OK)
             throw std::runtime_error(std::string("TileFarm: ") + ptrt_last_error(nullptr));
     }
+    // every part renders into its own image, asynchronously, on its device -- enqueued from one worker thread per part
+    // (ptrt_farm_parallel), since a part's host work (dirty checks, ptrt_render: 20-50 us) in a row would be of the order of
+    // an eighth of a frame on the GPU -- then the gather
     void frame(unsigned char *pixels, int is_device) {
-        for (auto &p : parts)
-            p->render_to_device(nullptr); // into the part's own image, asynchronously, on its device
+        const auto t0 = std::chrono::steady_clock::now();
+        errors.assign(parts.size(), std::string());
+        check(ptrt_farm_parallel(farm, [](int i, void *u) {
+            TileFarm *self = static_cast<TileFarm *>(u);
+            try {
+                self->parts[(size_t)i]->render_to_device(nullptr);
+            } catch (const std::exception &e) {
+                self->errors[(size_t)i] = e.what();
+            }
+        }, this));
+        for (const std::string &e : errors)
+            if (!e.empty())
+                throw std::runtime_error("TileFarm: " + e);
         check(ptrt_farm_gather(farm, pixels, is_device));
+        host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
+    std::vector<std::string> errors;
+    double host_us = 0.0;
+
+  public:
+    // host time (us) of the calling thread inside the last render_to_device / render_to_host
+    double hostMicroseconds() const { return host_us; }
+    void setParallel(bool on) { check(ptrt_farm_set_option(farm, "parallel", on ? 1 : 0)); }
 };

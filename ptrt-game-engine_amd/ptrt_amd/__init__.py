@@ -164,6 +164,8 @@ _sig("hs_farm_size", C.c_int, _vp)
 _sig("hs_farm_transport", C.c_char_p, _vp)
 _sig("hs_farm_render", C.c_int, _vp, _vp, C.c_int)
 _sig("hs_farm_sync", C.c_int, _vp)
+_sig("hs_farm_host_us", C.c_double, _vp)
+_sig("hs_farm_set_parallel", C.c_int, _vp, C.c_int)
 _sig("hs_farm_destroy", None, _vp)
 _sig("ptrt_create_interleaved", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp))
 _sig("ptrt_farm_create", C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp))
@@ -665,6 +667,15 @@ class TileFarm:
         if lib.hs_farm_render(self._f, out.ctypes.data_as(_vp), 0) < 0:
             raise PtrtError(lib.hs_last_error().decode())
         return out
+
+    @property
+    def host_us(self):
+        """Host time (us) the calling thread spent inside the last render (every part's enqueue + the gather's calls)."""
+        return float(lib.hs_farm_host_us(self._f))
+
+    def set_parallel(self, on):
+        if lib.hs_farm_set_parallel(self._f, int(bool(on))) < 0:
+            raise PtrtError(lib.hs_last_error().decode())
 
     def sync(self):
         if lib.hs_farm_sync(self._f) < 0:

@@ -80,3 +80,95 @@ def test_c_abi_farm_over_interleaved_contexts_and_bad_tilings(P):
     for s in parts + [a, b]:
         s.close()
     P.lib.ptrt_farm_destroy(None)
+
+
+def test_farm_enqueues_its_parts_in_parallel_and_says_what_the_host_paid(P):
+    """Eight strip parts on this one GPU: the frame's per-part host work (dirty checks + ptrt_render per Scene) runs on one
+    worker thread per part (ptrt_farm_parallel).  Same bytes with the workers and with the parts in a row, and the calling
+    thread's time inside a frame (TileFarm::hostMicroseconds) is reported -- the figure that must stay well below an
+    eighth of a frame's GPU time at N = 8.  (The bound here is loose: the box shares its cores.)"""
+    import torch
+    W, H, n = 256, 144, 8
+    farm = P.TileFarm(W, H, [0] * n, strips=True)
+    for s in farm.scenes:
+        _prep(P, s, P.scenes.cornell, spp=1)
+    dev = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    frames, host = {}, {}
+    for mode in (1, 0):
+        farm.set_parallel(bool(mode))
+        for s in farm.scenes:
+            s.reset_rng(P.DEFAULT_SEED)
+            s.setFrameCount(0)
+        got, us = [], []
+        for f in range(40):
+            farm.render_to_device(dev.data_ptr())
+            us.append(farm.host_us)
+            if f < 3:
+                farm.sync()
+                got.append(dev.cpu().numpy().copy())
+        farm.sync()
+        frames[mode], host[mode] = got, float(np.median(us[8:]))
+    for a, b in zip(frames[1], frames[0]):
+        assert np.array_equal(a, b)
+    assert frames[1][0].any()
+    print(f"TileFarm host time per frame, {n} parts: parallel {host[1]:.1f} us, in a row {host[0]:.1f} us")
+    assert 0.0 < host[1] < 2000.0 and 0.0 < host[0] < 4000.0
+    farm.close()
+
+
+def test_c_abi_farm_host_time_and_options(P):
+    W, H = 128, 72
+    parts = [P.Scene(W, H, interleave=(r, 4)) for r in range(4)]
+    for s in parts:
+        _prep(P, s, P.scenes.cornell, spp=1)
+        s.render_to_host()
+        s.reset_rng(P.DEFAULT_SEED)
+    farm = C.c_void_p()
+    assert P.lib.ptrt_farm_create((C.c_void_p * 4)(*[s.ctx for s in parts]), 4, C.byref(farm)) == 0
+    P.lib.ptrt_farm_host_us.restype = C.c_double
+    P.lib.ptrt_farm_host_us.argtypes = [C.c_void_p]
+    P.lib.ptrt_farm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+    assert P.lib.ptrt_farm_host_us(farm) == 0.0
+    out = [np.zeros((H, W, 3), np.uint8) for _ in range(2)]
+    assert P.lib.ptrt_farm_render(farm, 0, 1, 4, out[0].ctypes.data_as(C.c_void_p), 0) == 0
+    assert P.lib.ptrt_farm_host_us(farm) > 0.0
+    assert P.lib.ptrt_farm_set_option(farm, b"parallel", 0) == 0 and P.lib.ptrt_farm_set_option(farm, b"spin_us", 50) == 0
+    assert P.lib.ptrt_farm_set_option(farm, b"nonsense", 1) == -1
+    for s in parts:
+        s.reset_rng(P.DEFAULT_SEED)
+    assert P.lib.ptrt_farm_render(farm, 0, 1, 4, out[1].ctypes.data_as(C.c_void_p), 0) == 0
+    assert np.array_equal(out[0], out[1]) and out[0].any()
+    # a part that fails (spp 0) fails the frame with the part's message
+    assert P.lib.ptrt_farm_set_option(farm, b"parallel", 1) == 0
+    assert P.lib.ptrt_farm_render(farm, 0, 0, 4, out[1].ctypes.data_as(C.c_void_p), 0) != 0
+    assert b"part" in P.lib.ptrt_last_error(None)
+    P.lib.ptrt_farm_destroy(farm)
+    for s in parts:
+        s.close()
+
+
+def test_farm_into_a_presentation_ring_slot(P):
+    """The farm + viewer loop of farm.hpp: map a ring slot, gather the parts into it, unmap, acquire -- the host frame that
+    arrives is the frame (the slot's download waits for the gather's copies, which run on the farm's own stream)."""
+    W, H, n = 192, 104, 4
+    build = lambda s: P.scenes.showcase(s, segments=8)
+    full = P.Scene(W, H)
+    _prep(P, full, build)
+    want = [full.render_to_host() for _ in range(4)]
+    full.close()
+    farm = P.TileFarm(W, H, [0] * n, strips=True)
+    for s in farm.scenes:
+        _prep(P, s, build)
+    ring = C.c_void_p()
+    assert P.lib.ptrt_ring_create(0, W * H * 3, 2, C.byref(ring)) == 0
+    for f in range(4):
+        d = C.c_void_p()
+        assert P.lib.ptrt_ring_map(ring, f % 2, C.byref(d)) == 0 and d.value
+        farm.render_to_device(d.value)
+        assert P.lib.ptrt_ring_unmap(ring, f % 2) == 0
+        h = C.c_void_p()
+        assert P.lib.ptrt_ring_acquire(ring, f % 2, C.byref(h)) == 0 and h.value
+        got = np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_ubyte)), shape=(H, W, 3)).copy()
+        assert np.array_equal(got, want[f]), f"frame {f}: {(got != want[f]).sum()} bytes differ"
+    P.lib.ptrt_ring_destroy(ring)
+    farm.close()

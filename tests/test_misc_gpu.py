@@ -187,8 +187,9 @@ def test_full_size_traversal_variants_agree(P, scene):
     #  the async / wavefront kernels take single-leaf TLASes only and fall back to the same default there)
     # merged=0: separate closest-hit and any-hit phases (PMODE 2) instead of one traversal per iteration (PMODE 4)
     # lds_nodes=1: four tiles per workgroup sharing an LDS copy of the mesh heads and of the BLAS top levels
-    # pm1_wg=1: one tile per workgroup where the default gives two tiles one LDS copy of a small scene (PMODE 1)
-    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=1)):
+    # pm1_wg=2: two tiles per workgroup sharing one LDS copy of a small scene, six waves per SIMD (PMODE 1)
+    # tlas_rounds=1: shadow rays behind a real TLAS take one leaf per fill (the path of scenes with more than 1024 meshes)
+    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):
             for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):

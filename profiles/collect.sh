@@ -1,12 +1,12 @@
 #!/bin/bash
 # GPU box, repo root: the profile set of a round (RND, default r03) (kernel stats + PMC passes per config, lane occupancy of the instrumented
-# build).  Afterwards, in the build container:  for c in cornell1080 showcase1080 fluid many; do
+# build; `balanced` = Cornell with the denoiser + bloom chain).  Afterwards, in the build container:  for c in cornell1080 showcase1080 fluid many; do
 #   python profiles/summarize.py $c r03 $c; done   and   cp gpurun_out/prof_lane/lane_occupancy.txt profiles/r03_lane_occupancy.txt
 R=$PWD; V=ptrt-game-engine_amd/build/variants
-CFGS=${1:-"cornell1080 showcase1080 fluid many"}
+CFGS=${1:-"cornell1080 showcase1080 fluid many balanced"}
 mkdir -p gpurun_out/prof_lane
 for c in $CFGS; do
-  if [ $c = many ]; then bash profiles/pmc_pass.sh many --scene many; else bash profiles/pmc_pass.sh $c --config $c; fi
+  if [ $c = many ]; then bash profiles/pmc_pass.sh many --scene many; elif [ $c = balanced ]; then bash profiles/pmc_pass.sh balanced --preset balanced; else bash profiles/pmc_pass.sh $c --config $c; fi
   echo "pmc $c done"
 done
 cd $R

@@ -382,6 +382,7 @@ def main():
                     help="fluid scene: new vertex positions from HBM (default), from pinned host memory (H2D inside the step), or "
                          "through the reference's caller: updatePTScene's vertex rewrite + commitObjectChanges()")
     ap.add_argument("--via-commit", action="store_true", help="= --fluid-source commit")
+    ap.add_argument("--farm-serial", action="store_true", help="--farm: enqueue the parts in a row from the calling thread (A/B)")
     ap.add_argument("--rebuild", action="store_true",
                     help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
     args = ap.parse_args()
@@ -467,6 +468,8 @@ def main():
             sc.setBloomEnabled(False)
             sc.initBlueNoise()
             sc.uploadToGPU()
+        if args.farm_serial:
+            tf_.set_parallel(False)
         target = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
         for _ in range(args.warmup):
             tf_.render_to_device(target.data_ptr())
@@ -533,7 +536,8 @@ def main():
         out["config"]["fluid_source"] = args.fluid_source
     if farm_ms is not None:
         out["config"]["farm_ms_per_frame"] = round(farm_ms, 4)
-        out["config"]["farm"] = f"{args.farm} parts, {args.layout}, one process, transport {farm_transport}"
+        out["config"]["farm"] = (f"{args.farm} parts, {args.layout}, one process, transport {farm_transport}, parts enqueued "
+                                 + ("in a row" if args.farm_serial else "from one worker thread each"))
         out["config"]["farm_host_us_per_frame"] = round(sorted(farm_host)[len(farm_host) // 2], 1)
     if present is not None:
         out["config"]["present_ms_per_frame"] = round(present, 4)

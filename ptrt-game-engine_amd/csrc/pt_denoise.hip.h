@@ -173,6 +173,10 @@ PT_DEV float blend1(float a, float b, float c, float d, const Taps &t) {
 
 // cur4: firefly-filtered image.  ph1/ph2/pg4/pobj: last frame's history and G-buffer (on the first
 // frame the history IS the current frame: mean = cur, m2 = cur^2, len = 1, G = current).
+// (Round 3, measured and dropped: every load of this kernel -- the 3x3 neighbourhood's colours, the four taps' G-buffer
+// entries, ids and histories, the nearest texel -- issued up front and unconditionally, since every address is known before any
+// test: 112-114 us against 103-116 as written, at 94 instead of 72 VGPRs.  Its 80 % of wave-cycles in s_waitcnt are not the
+// dependent chains of the source.)
 __global__ __launch_bounds__(256) void temporal_kernel(float4 *__restrict__ oh1, float4 *__restrict__ oh2,
                                                        const float4 *__restrict__ cur4, const float4 *__restrict__ ph1,
                                                        const float4 *__restrict__ ph2, const float *__restrict__ motion,
@@ -381,9 +385,13 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                 const int e = ey * span + ex;
                 if (px >= 0 && px < W && yd >= 0 && py < H) {
                     const int pi = py * W + px;
+                    const float4 gv = g4[pi];
                     s_c[e] = in_c4[pi];
-                    s_g[e] = g4[pi];
-                    s_o[e] = uo ? object_id[pi] : 0;
+                    s_g[e] = gv;
+                    // (a sky pixel is skipped by every tap that reaches it, whatever its other tests say -- the reference's
+                    // `continue`s have no side effects --, so it is marked like a pixel outside the image, once, here,
+                    // instead of being re-derived by each of the up to 25 taps that read it: 90 -> 86 us per pass)
+                    s_o[e] = is_sky(gv.w, xyz(gv), sky) ? AT_OUTSIDE : (uo ? object_id[pi] : 0);
                 } else {
                     s_o[e] = AT_OUTSIDE;
                 }
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                     far = unsure ? (dd / max_d > edt) : far;
                 ok = ok && !(max_d > 1e-6f && far);
                 const f3 nn = xyz(ng);
-                ok = ok && !(dot(cn, nn) < ent) && !is_sky(ng.w, nn, sky);
+                ok = ok && !(dot(cn, nn) < ent); // (a sky neighbour carries AT_OUTSIDE: staging)
                 if (ok) {
                     const f3 nc = xyz(nc4);
                     const float ld = __builtin_fabsf(clum - luminance(nc));

@@ -289,7 +289,8 @@ PT_DEV int build_pairs(const KParams &K, const PairLds &L, int lane, bool alive,
     else
         L.best[lane] = ~0ull;
     // (the mesh heads come out of LDS, staged at kernel start: read from memory here -- mesh id, then its record, one
-    // dependent round trip each -- the loop took ~0.7 us per mesh and ~25 % of a showcase wave's time)
+    // dependent round trip each -- the loop took ~0.7 us per mesh and ~25 % of a showcase wave's time.  Reading head i + 1
+    // while mesh i's box is tested was measured in round 3: Cornell 1.81 -> 1.85 ms, the registers cost more than the round trip)
     int base = 0;
     for (int i = 0; i < K.pair_meshes; ++i) {
         const MeshHead mh = staged_mesh_head(L, i);

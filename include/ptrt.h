@@ -384,7 +384,15 @@ int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);
  * glfw_view_interop.hpp:281), else a host buffer (synchronous copy).  NULL skips
  * the copy (the RGB8 image stays readable through PTRT_BUF_RGB8).
  * Asynchronous w.r.t. the host when out_is_device != 0 or out_rgb8 == NULL, like
- * the reference (it returns right after the tonemap launch). */
+ * the reference (it returns right after the tonemap launch).
+ * out_is_device == PTRT_OUT_DEVICE_FRAME (ABI 5): out_rgb8 is the WHOLE width*height*3 frame (bottom-up) on the context's
+ * device and a band / strip context writes its rows where they belong in it -- several contexts on one device fill one
+ * frame without a copy (the tile farm does this for the parts on the presenting device).  Not with the denoiser, bloom or a
+ * reduced render size; PTRT_BUF_RGB8 then has nothing to read; a presentation-ring slot used this way is marked by the caller
+ * that joins the contexts (ptrt_farm_*), not by ptrt_render. */
+#define PTRT_OUT_HOST 0
+#define PTRT_OUT_DEVICE 1
+#define PTRT_OUT_DEVICE_FRAME 2
 int ptrt_render(ptrt_ctx *ctx, int frame_index, int spp, int max_depth, void *out_rgb8,
                 int out_is_device);
 
@@ -447,10 +455,15 @@ int ptrt_farm_gather(ptrt_farm *farm, void *out_rgb8, int out_is_device);
  *                        when all are back; fn must not throw.  ptrt_farm_render uses it for its ptrt_render calls, the
  *                        C++ TileFarm for its Scene::render_to_device calls.
  *   ptrt_farm_host_us    host time (us) of the caller's thread inside the last ptrt_farm_render
+ *   ptrt_farm_device_frame  the device frame a gather into (out_rgb8, out_is_device) assembles: out_rgb8 itself, or the
+ *                        farm's own frame when the target is host memory.  A context on the presenting device that rendered
+ *                        straight into it (ptrt_render(..., frame, PTRT_OUT_DEVICE_FRAME), as ptrt_farm_render makes them do)
+ *                        is not copied by the gather, only waited for
  *   ptrt_farm_set_option "parallel" 0|1 (default 1), "spin_us" (a worker polls that long for the next frame before it
  *                        sleeps; default 2000) */
 int ptrt_farm_parallel(ptrt_farm *farm, void (*fn)(int part, void *user), void *user);
 double ptrt_farm_host_us(const ptrt_farm *farm);
+void *ptrt_farm_device_frame(ptrt_farm *farm, void *out_rgb8, int out_is_device);
 int ptrt_farm_set_option(ptrt_farm *farm, const char *name, long long value);
 int ptrt_farm_sync(ptrt_farm *farm);
 void ptrt_farm_destroy(ptrt_farm *farm);
@@ -474,6 +487,7 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)
  *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9
+ *   time_kernels 0|1      1 (default): two events around the trace kernel feed ptrt_kernel_ms_history / ptrt_last_kernel_ms
  *   denoiser_active, motion_vectors, use_graphs 0|1 */
 int ptrt_set_option(ptrt_ctx *ctx, const char *name, long long value);
 /* Reads an option back, and -- read-only -- what the last ptrt_render launched, so that a measurement can name the kernel it

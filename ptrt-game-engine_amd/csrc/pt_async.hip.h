@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
                         if (K.rgb8) {
                             unsigned char r8, g8, b8;
                             tonemap_pixel(out, r8, g8, b8);
-                            const size_t o = ((size_t)(K.rows - 1 - yl) * K.width + x) * 3;
+                            const size_t o = ((size_t)rgb8_row(K, yl) * K.width + x) * 3;
                             K.rgb8[o + 0] = r8;
                             K.rgb8[o + 1] = g8;
                             K.rgb8[o + 2] = b8;

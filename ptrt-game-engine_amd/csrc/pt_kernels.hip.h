@@ -110,6 +110,8 @@ struct KParams {
     float *accum, *normal, *depth;
     int *object_id;
     unsigned char *rgb8;
+    int rgb8_frame; // 0: rgb8 is this context's own image (its rows, bottom-up); 1: rgb8 is the whole W x H frame (bottom-up) and
+                    // the context writes its rows where they belong in it (ptrt_render, PTRT_OUT_DEVICE_FRAME)
     unsigned long long *counters; // COUNTER_WORDS per slot: {extension, shadow, paths, zero-valued light samples} or nullptr
 };
 constexpr int COUNTER_WORDS = 4;
@@ -117,6 +119,11 @@ constexpr int COUNTER_WORDS = 4;
 // frame row of a context's local row: contiguous rows from y0, or every il_period-th 8-row strip from strip il_phase
 PT_DEV int global_row(int yl, int y0, int il_period, int il_phase) {
     return il_period > 1 ? ((((yl >> 3) * il_period + il_phase) << 3) | (yl & 7)) : y0 + yl;
+}
+
+// byte row of the RGB8 target that the context's local row yl goes to (both images are bottom-up)
+PT_DEV int rgb8_row(const KParams &K, int yl) {
+    return K.rgb8_frame ? K.height - 1 - global_row(yl, K.y0, K.il_period, K.il_phase) : K.rows - 1 - yl;
 }
 
 constexpr int MESH_REC_F4 = 12;

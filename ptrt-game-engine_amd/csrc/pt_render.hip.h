@@ -2022,11 +2022,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             const unsigned long long two = (unsigned long long)(uint32_t)__shfl((int)pix, src) |
                                            ((unsigned long long)(uint32_t)__shfl((int)pix, src1) << 24);
             if (c < 6) {
-                uint32_t *row = (uint32_t *)(KZ.rgb8 + ((size_t)(KZ.rows - 1 - yl) * KZ.width + (size_t)tx * 8) * 3);
+                uint32_t *row = (uint32_t *)(KZ.rgb8 + ((size_t)rgb8_row(KZ, yl) * KZ.width + (size_t)tx * 8) * 3);
                 row[c] = (uint32_t)(two >> (8 * ((4 * c) % 3)));
             }
         } else if (inside) {
-            const size_t o = ((size_t)(KZ.rows - 1 - yl) * KZ.width + x) * 3;
+            const size_t o = ((size_t)rgb8_row(KZ, yl) * KZ.width + x) * 3;
             KZ.rgb8[o + 0] = r8;
             KZ.rgb8[o + 1] = g8;
             KZ.rgb8[o + 2] = b8;

@@ -57,6 +57,8 @@ struct ptrt_ctx {
     int *d_object_id = nullptr;
     unsigned char *d_rgb8 = nullptr;
     unsigned char *last_rgb8 = nullptr; // where the last frame's RGB8 went
+    void *last_frame_target = nullptr;  // ... or the caller's frame it was written into (PTRT_OUT_DEVICE_FRAME)
+    int time_kernels = 1;               // option: record the two events per launch that ptrt_kernel_ms_history reads
     unsigned long long *d_counters = nullptr; // n_counter_slots x pt::COUNTER_WORDS {extension rays, shadow rays, paths, zero-valued light samples}
     size_t n_counter_slots = 0;
     float2 *d_blue = nullptr;
@@ -1953,9 +1955,16 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     K.max_depth = max_depth;
     K.frame_count = frame_index;
     unsigned char *frame_rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
-    c->last_rgb8 = frame_rgb8;
     // the stage that produces the final HDR image also tonemaps it; earlier stages skip theirs
     const bool scaled = c->scaled(), denoise = c->dn_on && c->dn_active, bloom = c->bloom_on != 0;
+    // PTRT_OUT_DEVICE_FRAME: out_rgb8 is the whole W x H frame on this device; a band / strip context writes its rows where
+    // they belong in it -- no image of its own, nothing for a tile farm to copy (ptrt_farm_*)
+    const bool into_frame = out_rgb8 && out_is_device == PTRT_OUT_DEVICE_FRAME;
+    if (into_frame && (denoise || bloom || scaled))
+        return fail(c, PTRT_E_INVALID, "ptrt_render: PTRT_OUT_DEVICE_FRAME with the denoiser, bloom or a reduced render size");
+    c->last_rgb8 = into_frame ? nullptr : frame_rgb8; // (a frame target is the caller's: ptrt_read_buffer(RGB8) has nothing to read)
+    c->last_frame_target = into_frame ? out_rgb8 : nullptr;
+    K.rgb8_frame = into_frame ? 1 : 0;
     K.rgb8 = (denoise || bloom || scaled) ? nullptr : frame_rgb8;
     if (c->count_rays)
         K.counters = c->d_counters;
@@ -2077,7 +2086,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         fprintf(stderr, "ptrt: pmode %d, %d meshes in the leaf, %d triangle slots, stack %d, LDS %zu + %zu bytes per workgroup\n", pmode,
                 c->pair_meshes, c->pair_tri_slots, c->stack_entries, lds, lds_main - lds);
     const int slot = (int)(c->launches % EV_RING);
-    HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
+    const bool timing = c->time_kernels || tuning;
+    if (timing)
+        HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
     c->last_mode = 0;
     if (async_applicable(c)) {
         if (int rc = run_async(c, K, full))
@@ -2117,14 +2128,15 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     else
         launch_trace<2, 0>(c, K, full, grid, lds);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
+    if (timing)
+        HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     if (tuning) {
         if (c->tune_n >= TUNE_WARM)
             c->tune_launch[c->tune_n - TUNE_WARM] = c->launches;
         ++c->tune_n;
     }
     c->launches++;
-    c->timed = true;
+    c->timed = timing;
     float *current = K.accum; // `current_image` of Scene::render_to_device (scene.cuh:1086)
     if (denoise) {
         if (int rc = run_denoiser(c, K, (bloom || scaled) ? nullptr : frame_rgb8))
@@ -2140,7 +2152,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                            c->d_accum, current, c->W, c->H, c->rw, c->rh, frame_rgb8);
         HIP_TRY(c, hipGetLastError());
     }
-    if (out_rgb8 && out_is_device)
+    if (out_rgb8 && out_is_device && !into_frame) // (a frame shared by several contexts is marked by whoever joins them)
         ring_mark_rendered(out_rgb8, c->stream);
     if (out_rgb8 && !out_is_device) {
         HIP_TRY(c, hipMemcpyAsync(out_rgb8, c->d_rgb8, c->npix * 3, hipMemcpyDeviceToHost, c->stream));
@@ -2435,6 +2447,8 @@ int ptrt_kernel_ms_history(ptrt_ctx *c, float *out_ms, int max_n) {
         return fail(c, PTRT_E_INVALID, "ptrt_kernel_ms_history: bad argument");
     if (int rc = set_device(c))
         return rc;
+    if (!c->time_kernels)
+        return 0; // (option time_kernels = 0: no events were recorded)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned long long n = c->launches < (unsigned long long)EV_RING ? c->launches : EV_RING;
     if (n > (unsigned long long)max_n)
@@ -2490,6 +2504,8 @@ int ptrt_read_buffer(ptrt_ctx *c, int kind, void *dst, size_t bytes) {
     }
     if (bytes < need)
         return fail(c, PTRT_E_INVALID, "ptrt_read_buffer: destination holds %zu bytes, need %zu", bytes, need);
+    if (kind == PTRT_BUF_RGB8 && !src) // (the last frame went straight into a caller's frame: PTRT_OUT_DEVICE_FRAME)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_read_buffer: the last frame was written into the caller's frame, the context holds no RGB8 image of it");
     if (kind == PTRT_BUF_RNG) {
         uint32_t *tmp = nullptr;
         HIP_TRY(c, hipMalloc((void **)&tmp, need));
@@ -2625,6 +2641,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
             return fail(c, PTRT_E_INVALID, "lds_pad must be 0..32768");
         c->lds_pad = (int)value;
     }
+    else if (n == "time_kernels") // 0: no start / stop events around the trace kernel (two driver calls per frame; ptrt_kernel_ms_history then has nothing)
+        c->time_kernels = value ? 1 : 0;
     else if (n == "tlas_rounds") // PMODE 3 shadow rays: one TLAS leaf per ray and fill instead of all of them (A/B, tests)
         c->tlas_rounds = value ? 1 : 0;
     else if (n == "pm1_wg") { // PMODE 1: one or two tiles per workgroup (0 = choose by the LDS budget; A/B, tests)
@@ -2671,7 +2689,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

@@ -319,7 +319,21 @@ int ptrt_farm_bands(const ptrt_farm *f) { return farm_live(const_cast<ptrt_farm 
 
 const char *ptrt_farm_transport(const ptrt_farm *f) { return farm_live(const_cast<ptrt_farm *>(f)) ? f->transport.c_str() : ""; }
 
-// Gathers the contexts' current RGB8 images (rendered with a NULL target) into the frame.
+// The device frame a gather into (out_rgb8, out_is_device) assembles: the caller's, or the farm's own for a host target.
+void *ptrt_farm_device_frame(ptrt_farm *f, void *out_rgb8, int out_is_device) {
+    if (!farm_live(f) || !out_rgb8)
+        return nullptr;
+    if (out_is_device)
+        return out_rgb8;
+    if (!f->d_frame) {
+        if (hipSetDevice(f->device) != hipSuccess || hipMalloc((void **)&f->d_frame, (size_t)f->W * f->H * 3) != hipSuccess)
+            return nullptr;
+    }
+    return f->d_frame;
+}
+
+// Gathers the contexts' current RGB8 images into the frame: a context on the presenting device that rendered straight
+// into the frame (PTRT_OUT_DEVICE_FRAME) is only waited for; one that rendered into its own image (a NULL target) is copied.
 int ptrt_farm_gather(ptrt_farm *f, void *out_rgb8, int out_is_device) {
     if (!farm_live(f) || !out_rgb8)
         return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_gather: bad argument");
@@ -327,13 +341,10 @@ int ptrt_farm_gather(ptrt_farm *f, void *out_rgb8, int out_is_device) {
         if (!ctx_live(c))
             return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_gather: a context of the farm has been destroyed");
     const size_t frame_bytes = (size_t)f->W * f->H * 3;
-    unsigned char *frame = (unsigned char *)out_rgb8;
+    unsigned char *frame = (unsigned char *)ptrt_farm_device_frame(f, out_rgb8, out_is_device);
+    if (!frame)
+        return fail(nullptr, PTRT_E_HIP, "ptrt_farm_gather: no device frame");
     HIP_TRY(nullptr, hipSetDevice(f->device));
-    if (!out_is_device) {
-        if (!f->d_frame)
-            HIP_TRY(nullptr, hipMalloc((void **)&f->d_frame, frame_bytes));
-        frame = f->d_frame;
-    }
     const size_t n = f->band.size();
     // remote images: sends on the contexts' streams (behind their render), receives on the farm's stream, one group
     if (!f->comms.empty()) {
@@ -354,19 +365,17 @@ int ptrt_farm_gather(ptrt_farm *f, void *out_rgb8, int out_is_device) {
     for (size_t i = 0; i < n; ++i) {
         ptrt_ctx *c = f->band[i];
         const unsigned char *src = f->staging[i];
-        if (f->comm_rank[i] < 0) { // on the presenting device: behind the context's render
-            HIP_TRY(nullptr, hipSetDevice(c->device));
+        if (f->comm_rank[i] < 0) { // on the presenting device (the current one): behind the context's render
             HIP_TRY(nullptr, hipEventRecord(f->rendered[i], c->stream));
-            HIP_TRY(nullptr, hipSetDevice(f->device));
             HIP_TRY(nullptr, hipStreamWaitEvent(f->stream, f->rendered[i], 0));
             src = c->d_rgb8;
         }
+        if (f->comm_rank[i] < 0 && c->last_frame_target == (void *)frame)
+            continue; // (its rows are already in the frame: the wait above is all the gather owes it)
         HIP_TRY(nullptr, place_image(c, src, frame, f->stream));
         if (f->comm_rank[i] < 0) { // its next render must not overwrite the image before it has been taken
             HIP_TRY(nullptr, hipEventRecord(f->taken[i], f->stream));
-            HIP_TRY(nullptr, hipSetDevice(c->device));
             HIP_TRY(nullptr, hipStreamWaitEvent(c->stream, f->taken[i], 0));
-            HIP_TRY(nullptr, hipSetDevice(f->device));
         }
     }
     if (!out_is_device) {
@@ -414,16 +423,21 @@ int ptrt_farm_render(ptrt_farm *f, int frame_index, int spp, int max_depth, void
     if (!farm_live(f))
         return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_render: bad farm");
     const auto t0 = std::chrono::steady_clock::now();
+    // parts on the presenting device write their rows straight into the device frame (no image of their own to copy)
+    void *dev_frame = out_rgb8 ? ptrt_farm_device_frame(f, out_rgb8, out_is_device) : nullptr;
     struct Job {
         ptrt_farm *f;
         int frame, spp, depth;
-    } job{f, frame_index, spp, max_depth};
+        void *dev_frame;
+    } job{f, frame_index, spp, max_depth, dev_frame};
     f->part_rc.assign(f->band.size(), PTRT_OK);
     f->part_err.assign(f->band.size(), std::string());
     const int prc = ptrt_farm_parallel(f, [](int i, void *u) {
         Job *j = static_cast<Job *>(u);
         ptrt_ctx *c = j->f->band[(size_t)i];
-        const int rc = ptrt_render(c, j->frame, j->spp, j->depth, nullptr, 0);
+        const bool local = j->f->comm_rank[(size_t)i] < 0 && j->dev_frame;
+        const int rc = local ? ptrt_render(c, j->frame, j->spp, j->depth, j->dev_frame, PTRT_OUT_DEVICE_FRAME)
+                             : ptrt_render(c, j->frame, j->spp, j->depth, nullptr, 0);
         j->f->part_rc[(size_t)i] = rc;
         if (rc != PTRT_OK)
             j->f->part_err[(size_t)i] = ptrt_last_error(c); // (the error text is per thread: carried back to the caller's)

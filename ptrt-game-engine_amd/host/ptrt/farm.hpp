@@ -39,6 +39,8 @@ class TileFarm {
             build(*parts.back());
             parts.back()->setDenoiserEnabled(false); // parts have no post chain (Scene::postFrameFromDevice does it on a gathered frame)
             parts.back()->setBloomEnabled(false);
+            // (no start / stop events around a part's kernel: two driver calls per part and frame that nobody reads)
+            ptrt_set_option(parts.back()->backend(), "time_kernels", 0);
         }
         std::vector<ptrt_ctx *> ctxs;
         for (auto &p : parts)
@@ -86,10 +88,16 @@ class TileFarm {
     void frame(unsigned char *pixels, int is_device) {
         const auto t0 = std::chrono::steady_clock::now();
         errors.assign(parts.size(), std::string());
+        // the parts on the presenting GPU write their rows straight into the device frame the gather assembles
+        dev_frame = static_cast<unsigned char *>(ptrt_farm_device_frame(farm, pixels, is_device));
         check(ptrt_farm_parallel(farm, [](int i, void *u) {
             TileFarm *self = static_cast<TileFarm *>(u);
             try {
-                self->parts[(size_t)i]->render_to_device(nullptr);
+                Scene &p = *self->parts[(size_t)i];
+                if (self->dev_frame && p.deviceIndex() == self->parts[0]->deviceIndex())
+                    p.render_to_frame(self->dev_frame);
+                else
+                    p.render_to_device(nullptr);
             } catch (const std::exception &e) {
                 self->errors[(size_t)i] = e.what();
             }
@@ -101,6 +109,7 @@ class TileFarm {
         host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
     std::vector<std::string> errors;
+    unsigned char *dev_frame = nullptr;
     double host_us = 0.0;
 
   public:

@@ -793,6 +793,10 @@ class Scene {
     // same frame into HOST memory (synchronous); the reference has no such call on
     // its PT Scene -- callers there map a GL buffer instead
     void render_to_host(unsigned char *host_pixels) { renderInternal(host_pixels, 0); }
+    // a band / strip scene's rows straight into the WHOLE frame (W*H*3 bytes, bottom-up, on this scene's device): what the
+    // tile farm does with the parts on the presenting GPU -- no image of their own, nothing to copy (ptrt.h PTRT_OUT_DEVICE_FRAME)
+    void render_to_frame(unsigned char *device_frame) { renderInternal(device_frame, PTRT_OUT_DEVICE_FRAME); }
+    int deviceIndex() const { return device_; }
 
     // Tile farm, presenting rank: the post chain of render_to_device over a frame gathered from band contexts
     // (device pointers, top-down; include/ptrt.h ptrt_post_frame).  Same bookkeeping as a rendered frame.

@@ -174,6 +174,9 @@ _sig("ptrt_farm_transport", C.c_char_p, _vp)
 _sig("ptrt_farm_render", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int)
 _sig("ptrt_farm_gather", C.c_int, _vp, _vp, C.c_int)
 _sig("ptrt_farm_sync", C.c_int, _vp)
+_sig("ptrt_farm_device_frame", _vp, _vp, _vp, C.c_int)
+_sig("ptrt_farm_host_us", C.c_double, _vp)
+_sig("ptrt_farm_set_option", C.c_int, _vp, C.c_char_p, C.c_longlong)
 _sig("ptrt_farm_destroy", None, _vp)
 _sig("hs_scene_destroy", None, _vp)
 _sig("hs_backend", _vp, _vp)

@@ -112,7 +112,7 @@ def test_farm_enqueues_its_parts_in_parallel_and_says_what_the_host_paid(P):
         assert np.array_equal(a, b)
     assert frames[1][0].any()
     print(f"TileFarm host time per frame, {n} parts: parallel {host[1]:.1f} us, in a row {host[0]:.1f} us")
-    assert 0.0 < host[1] < 2000.0 and 0.0 < host[0] < 4000.0
+    assert 0.0 < host[1] < 600.0 and 0.0 < host[0] < 600.0  # (measured: 58-70 us; the box shares its cores)
     farm.close()
 
 
@@ -172,3 +172,41 @@ def test_farm_into_a_presentation_ring_slot(P):
         assert np.array_equal(got, want[f]), f"frame {f}: {(got != want[f]).sum()} bytes differ"
     P.lib.ptrt_ring_destroy(ring)
     farm.close()
+
+
+def test_contexts_write_their_rows_straight_into_one_frame(P):
+    """ptrt_render(..., frame, PTRT_OUT_DEVICE_FRAME): three strip contexts and two band contexts on one device fill one
+    W x H frame without an image of their own -- the bytes of the full-frame context -- and the farm's gather then has
+    nothing to copy for them (what ptrt_farm_render and TileFarm do with the parts on the presenting GPU)."""
+    import torch
+    W, H = 88, 60  # 60 rows: strips 0..7, the last one 4 rows
+    build = P.scenes.cornell
+    full = P.Scene(W, H)
+    _prep(P, full, build, spp=2)
+    want = [full.render_to_host() for _ in range(2)]
+    full.close()
+    for parts in ([P.Scene(W, H, interleave=(r, 3)) for r in range(3)],
+                  [P.Scene(W, H, tile_y0=0, tile_rows=28), P.Scene(W, H, tile_y0=28, tile_rows=32)]):
+        for s in parts:
+            _prep(P, s, build, spp=2)
+            s.render_to_host()              # (camera and sky reach the context with the first frame)
+            s.reset_rng(P.DEFAULT_SEED)
+        frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        for f in range(2):
+            for s in parts:
+                assert P.lib.ptrt_render(s.ctx, f, 2, 4, C.c_void_p(frame.data_ptr()), 2) == 0
+                s.sync()
+            assert np.array_equal(frame.cpu().numpy(), want[f]), f
+        buf = np.zeros(parts[0].tile_rows * W * 3, np.uint8)
+        assert P.lib.ptrt_read_buffer(parts[0].ctx, P.BUF_RGB8, buf.ctypes.data_as(C.c_void_p), buf.nbytes) != 0  # nothing of its own
+        for s in parts:
+            s.close()
+    # not with a post chain: a full-frame context with bloom on refuses the frame target
+    s = P.Scene(96, 64)
+    _prep(P, s, build, spp=1)
+    s.setBloomEnabled(True)
+    s.render_to_host()
+    frame = torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda")
+    assert P.lib.ptrt_render(s.ctx, 1, 1, 4, C.c_void_p(frame.data_ptr()), 2) == -1
+    assert b"PTRT_OUT_DEVICE_FRAME" in P.lib.ptrt_last_error(s.ctx)
+    s.close()

@@ -384,7 +384,8 @@ int ptrt_upload_scene(ptrt_ctx *ctx, const ptrt_scene_desc *scene);
  * glfw_view_interop.hpp:281), else a host buffer (synchronous copy).  NULL skips
  * the copy (the RGB8 image stays readable through PTRT_BUF_RGB8).
  * Asynchronous w.r.t. the host when out_is_device != 0 or out_rgb8 == NULL, like
- * the reference (it returns right after the tonemap launch).
+ * the reference (it returns right after the tonemap launch).  Ordering on the context's stream: see option "pipeline" of
+ * ptrt_set_option -- the frame is complete before anything that follows the call on the stream, always.
  * out_is_device == PTRT_OUT_DEVICE_FRAME (ABI 5): out_rgb8 is the WHOLE width*height*3 frame (bottom-up) on the context's
  * device and a band / strip context writes its rows where they belong in it -- several contexts on one device fill one
  * frame without a copy (the tile farm does this for the parts on the presenting device).  Not with the denoiser, bloom or a
@@ -483,6 +484,19 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         blocks the host (a hipEventSynchronize on frame 9, once per scene and setting); set merged to 0 or 1
  *                         before the first frame to opt out.  Never taken while the stream is being captured into a hipGraph.
  *   stage 0..7            PMODE 1: shading inputs kept in LDS (0 none; else jitter inputs, |1 light records, |2 material records)
+ *   pipeline 0|1, split 1..4   frame pipelining (default 1, 2).  A frame whose launch need not wait for the stream is dealt, by rows
+ *                         of 8x8 tiles, to `split` launches on auxiliary streams of the context; launch i follows launch i of the
+ *                         previous frame (the same pixels) and the frame is joined onto the context's stream by events, so
+ *                         WHAT FOLLOWS ptrt_render ON THE STREAM STILL FOLLOWS THE FRAME -- but the frame itself may start while
+ *                         the previous frame's last waves drain and while work enqueued EARLIER on the stream still runs
+ *                         (Cornell 1080p 1.81 -> 1.68 ms, showcase 3.85 -> 3.57).  Only when nothing else can have a claim on
+ *                         what the frame reads or overwrites: a DEVICE target other than the previous frame's (double buffering:
+ *                         whatever consumes the previous target on the stream is still entitled to it), no denoiser / bloom /
+ *                         reduced size, no ptrt_* call since the previous ptrt_render other than the host-only ones
+ *                         (ptrt_set_camera / _sky / _option / _prev_view_proj, ptrt_get_option, ptrt_sync, ptrt_last_error,
+ *                         ptrt_set_bloom(0)), no pointer from ptrt_device_buffer in the caller's hands, not behind a real TLAS,
+ *                         not while the loop shape is being sampled or the stream captured.  Any other frame is ONE launch
+ *                         ordered behind the stream, as with pipeline = 0.  ptrt_get_option "pipelined" says which the last one was.
  *   tlas_rounds 0|1       real TLAS: shadow rays take one TLAS leaf per fill of the pair list (what > 1024 meshes use) instead of all
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)

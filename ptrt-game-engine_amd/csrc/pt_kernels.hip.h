@@ -103,6 +103,8 @@ struct KParams {
     int y0, rows;      // tile
     int il_period, il_phase; // > 1: the context owns the 8-row strips `phase, phase + period, ...` of the frame (global_row)
     int tiles_x;
+    int split_n, split_i; // the frame's tile ROWS are dealt to split_n concurrent launches (0 / 1: one launch); this one takes rows
+                          // split_i, split_i + split_n, ...
     int spp, max_depth, frame_count;
     // buffers (tile-sized)
     uint32_t *rng;    // 6 planes of rng_plane words (the context's rows*width; larger than the frame at a reduced render size)

@@ -1545,7 +1545,10 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     const bool no_tile = WG > 1 && tile >= K.n_tiles;
     if (PMODE != 1 && no_tile)
         return; // (after the workgroup's only barrier)
-    const int tx = no_tile ? 0 : tile % K.tiles_x, ty = no_tile ? 0 : tile / K.tiles_x;
+    // (a frame dealt to several concurrent launches, ptrt_set_option "split": this launch's k-th row of tiles is row
+    // split_i + k * split_n of the frame; the counters' slot follows the frame's numbering)
+    const int tx = no_tile ? 0 : tile % K.tiles_x;
+    const int ty = no_tile ? 0 : (K.split_n > 1 ? (tile / K.tiles_x) * K.split_n + K.split_i : tile / K.tiles_x);
     // Registers are what this kernel runs out of (128 per lane at four waves per SIMD; what does not fit is spilled to
     // scratch, and a reload is a trip to the L2).  State that is only touched when a path starts or ends stays out of
     // them: the pixel's coordinates are recomputed from the lane id where they are needed (the empty asm keeps the
@@ -2047,7 +2050,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         // serialised at the L2 atomic unit: 97 K of them took 1.2 ms per 1080p frame -- hidden behind a
         // 2.7-ms trace, but the whole cost of a light frame (1 spp, 1 bounce: 1.19 ms -> 0.17 ms).
         if (lane == 0) {
-            unsigned long long *w = KZ.counters + (size_t)tile * COUNTER_WORDS;
+            unsigned long long *w = KZ.counters + (size_t)(ty * KZ.tiles_x + tx) * COUNTER_WORDS;
             w[0] += (unsigned long long)a;
             w[1] += (unsigned long long)b;
             w[2] += (unsigned long long)c;

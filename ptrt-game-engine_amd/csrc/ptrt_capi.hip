@@ -171,6 +171,20 @@ struct ptrt_ctx {
     // waves per SIMD on 80 VGPRs -- measured on Cornell 1080p: 1.875 vs 1.877 ms, the 112 B per lane it spills eat what 24
     // instead of 20 waves per CU bring.  0: two when the scene fits that budget.
     int pm1_wg = 1;
+    // option "split": the frame's tile rows dealt to that many launches on auxiliary streams of the context (forked from and
+    // joined to its stream by events, so the caller still sees one stream).  Concurrent launches of ONE frame buy nothing
+    // (Cornell 1080p 1.85 vs 1.82 ms); what they make possible is option "pipeline": frame N + 1's launches follow frame N's
+    // on their own streams and do not wait for the rest of frame N to drain -- 1.81 -> 1.66 ms (see ptrt_render).
+    int split = 2, split_eff = 1, pipeline = 1;
+    static constexpr int MAX_SPLIT = 4;
+    hipStream_t aux_stream[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t split_fork = nullptr, split_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
+    bool touched = true;          // an entry point that may enqueue device work ran since the last ptrt_render (ctx_live)
+    bool escaped = false;         // ptrt_device_buffer handed out pointers into the context's buffers
+    void *prev_out = nullptr;     // the previous frame's device target
+    hipStream_t prev_stream = nullptr;
+    int prev_split = 0;
+    bool pipelined_last = false;  // the last frame's launches did not wait for the stream (ptrt_get_option "pipelined")
     int tlas_rounds = 0; // option (A/B, tests): PMODE 3 shadow rays take one TLAS leaf per fill, as scenes with > 1024 meshes do
     int stage = 7; // PMODE 1, shading inputs staged in LDS: 0 none, else jitter table + blue noise, | 1 lights, | 2 materials
     int lds_nodes = 0; // option: PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels (measured slower: DESIGN.md 3.1)
@@ -589,11 +603,24 @@ int pick_geom(ptrt_ctx *c) {
     return g;
 }
 
-template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams &K, bool full, int grid, size_t lds) {
-    if (full)
-        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE>), dim3(grid), dim3(64), lds, c->stream, K);
-    else
-        hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PMODE>), dim3(grid), dim3(64), lds, c->stream, K);
+// One 8x8 tile per 64-thread workgroup.  The frame's tile rows may be dealt to `c->split_eff` launches that run concurrently
+// on the context's stream and its auxiliary streams (forked and joined by events around them: render_split_begin / _end).
+template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams &K0, bool full, int grid, size_t lds) {
+    const int n = c->split_eff > 1 ? c->split_eff : 1;
+    const int tiles_y = grid / K0.tiles_x;
+    for (int i = 0; i < n; ++i) {
+        pt::KParams K = K0;
+        K.split_n = n;
+        K.split_i = i;
+        const int g = n > 1 ? K0.tiles_x * ((tiles_y - i + n - 1) / n) : grid;
+        if (g <= 0)
+            continue;
+        hipStream_t st = n > 1 ? c->aux_stream[i] : c->stream;
+        if (full)
+            hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE>), dim3(g), dim3(64), lds, st, K);
+        else
+            hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PMODE>), dim3(g), dim3(64), lds, st, K);
+    }
 }
 
 // in-wave (ray, mesh) pair compaction needs every BLAS to be one leaf and the staged
@@ -753,9 +780,15 @@ int run_async(ptrt_ctx *c, const pt::KParams &K, bool full) {
     return PTRT_OK;
 }
 
-bool ctx_live(ptrt_ctx *c) {
+// `device_work`: the caller may enqueue work on the context's stream or change what its kernels read from memory -- every
+// entry point except the few host-only ones below.  The next ptrt_render then orders its launches behind the stream (see
+// "pipeline" there) instead of overlapping them with the previous frame's.
+bool ctx_live(ptrt_ctx *c, bool device_work = true) {
     std::lock_guard<std::mutex> lock(g_live_mutex);
-    return c && g_live.count(c);
+    const bool live = c && g_live.count(c);
+    if (live && device_work)
+        c->touched = true;
+    return live;
 }
 
 // ---- dynamic geometry: launch sequences, replayed as hipGraphs ------------------------------
@@ -1007,7 +1040,7 @@ extern "C" {
 int ptrt_abi_version(void) { return PTRT_ABI_VERSION; }
 
 const char *ptrt_last_error(const ptrt_ctx *ctx) {
-    if (ctx && ctx_live(const_cast<ptrt_ctx *>(ctx)))
+    if (ctx && ctx_live(const_cast<ptrt_ctx *>(ctx), false))
         return ctx->err.c_str();
     return g_last_error.c_str();
 }
@@ -1127,6 +1160,16 @@ void ptrt_destroy(ptrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < ptrt_ctx::MAX_SPLIT; ++i) { // the auxiliary streams of split launches
+        if (c->aux_stream[i]) {
+            (void)hipStreamSynchronize(c->aux_stream[i]);
+            (void)hipStreamDestroy(c->aux_stream[i]);
+        }
+        if (c->split_join[i])
+            (void)hipEventDestroy(c->split_join[i]);
+    }
+    if (c->split_fork)
+        (void)hipEventDestroy(c->split_fork);
     free_scene(c);
     dfree(c->d_materials);
     dfree(c->d_lights);
@@ -1632,7 +1675,7 @@ int ptrt_upload_lights(ptrt_ctx *c, const ptrt_light *lights, int n) {
 }
 
 int ptrt_set_camera(ptrt_ctx *c, const ptrt_camera *cam) {
-    if (!ctx_live(c) || !cam)
+    if (!ctx_live(c, false) || !cam)
         return fail(c, PTRT_E_INVALID, "ptrt_set_camera: bad argument");
     auto v = [](const ptrt_vec3 &a) { return pt::f3{a.x, a.y, a.z}; };
     c->cam.origin = v(cam->origin);
@@ -1647,7 +1690,7 @@ int ptrt_set_camera(ptrt_ctx *c, const ptrt_camera *cam) {
 }
 
 int ptrt_set_sky(ptrt_ctx *c, const ptrt_vec3 *top, const ptrt_vec3 *bottom, int use_sky) {
-    if (!ctx_live(c))
+    if (!ctx_live(c, false))
         return fail(c, PTRT_E_INVALID, "ptrt_set_sky: bad context");
     if (top)
         c->sky_top = pt::f3{top->x, top->y, top->z};
@@ -1870,7 +1913,7 @@ int ptrt_denoiser_disable(ptrt_ctx *c) {
 }
 
 int ptrt_set_prev_view_proj(ptrt_ctx *c, const float *m16) {
-    if (!ctx_live(c) || !m16)
+    if (!ctx_live(c, false) || !m16)
         return fail(c, PTRT_E_INVALID, "ptrt_set_prev_view_proj: bad argument");
     std::memcpy(c->prev_view_proj, m16, sizeof c->prev_view_proj);
     return PTRT_OK;
@@ -1910,12 +1953,13 @@ int ptrt_set_render_size(ptrt_ctx *c, int render_w, int render_h) {
 }
 
 int ptrt_set_bloom(ptrt_ctx *c, int enabled) {
-    if (!ctx_live(c))
+    if (!ctx_live(c, false))
         return fail(c, PTRT_E_INVALID, "ptrt_set_bloom: bad context");
     if (!enabled) {
         c->bloom_on = 0; // the mips stay allocated, as in the reference
         return PTRT_OK;
     }
+    c->touched = true;
     if (c->rows != c->H || c->y0 != 0)
         return fail(c, PTRT_E_INVALID, "ptrt_set_bloom: bloom needs a full-frame context (its blur reads across band "
                                        "borders); apply it on the presenting rank instead");
@@ -1936,7 +1980,7 @@ int ptrt_set_bloom(ptrt_ctx *c, int enabled) {
 }
 
 int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
-    if (!ctx_live(c))
+    if (!ctx_live(c, false))
         return fail(c, PTRT_E_INVALID, "ptrt_render: bad context");
     if (!c->have_geometry || !c->have_materials)
         return fail(c, PTRT_E_NOT_READY, "ptrt_render: %s not uploaded", c->have_geometry ? "materials" : "geometry");
@@ -2089,6 +2133,45 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const bool timing = c->time_kernels || tuning;
     if (timing)
         HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
+    // Options "split" / "pipeline": frame pipelining.  A frame ends with a tail -- its last waves drain while most of the chip
+    // idles, then the next launch ramps up: ~8 % of a 1080p Cornell frame.  With the frame's rows of tiles dealt to `split`
+    // launches on auxiliary streams, launch i of frame N + 1 touches the same pixels (generator states, accumulators, image
+    // rows) as launch i of frame N and nothing else of that frame, so it only has to follow THAT launch, which it does on
+    // its stream; it need not wait for the stream the caller sees, onto which every frame is joined by events.  That is safe
+    // only while nothing else has a claim on what it reads or overwrites: no entry point that could have enqueued device work
+    // or changed device data since the last frame (`touched`, set by ctx_live), no post chain reading the HDR image on the
+    // stream, no pointers into the context's buffers in the caller's hands, no loop-shape sampling (it times launches), no
+    // per-frame preparation on the stream (PMODE 3's head gather), not while the caller records the stream into a graph, and
+    // a DEVICE target other than the previous frame's (whatever consumes that one on the stream is still entitled to it).
+    // A frame that cannot overlap is ONE launch on the context's stream, as ever (concurrent launches of one frame buy
+    // nothing: Cornell 1.85 vs 1.82 ms) -- followed by an event the next frame's launches wait for if that one can.
+    c->split_eff = 1;
+    c->pipelined_last = false;
+    const int n_split = c->split < ptrt_ctx::MAX_SPLIT ? c->split : ptrt_ctx::MAX_SPLIT;
+    const bool splittable = c->pipeline && n_split > 1 && tiles_y >= 2 * n_split && !async_applicable(c) &&
+                            !wavefront_applicable(c, spp, max_depth) && !(pmode == 1 && pm1_wg == 2) &&
+                            !(pmode == 2 && c->lds_nodes && c->stack_entries > 0) && pmode != 3;
+    if (splittable && !c->touched && !c->escaped && !tuning && !(denoise || bloom || scaled) && out_rgb8 && out_is_device &&
+        out_rgb8 != c->prev_out && c->prev_stream == c->stream && c->prev_split > 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess)
+            (void)hipGetLastError();
+        if (cs == hipStreamCaptureStatusNone) {
+            for (int i = 0; i < n_split; ++i)
+                if (!c->aux_stream[i]) {
+                    HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking));
+                    HIP_TRY(c, hipEventCreateWithFlags(&c->split_join[i], hipEventDisableTiming));
+                }
+            if (c->prev_split != n_split) // the previous frame was one launch on the stream: follow it (and only it)
+                for (int i = 0; i < n_split; ++i)
+                    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream[i], c->split_fork, 0));
+            c->split_eff = n_split;
+            c->pipelined_last = true;
+        }
+    }
+    c->prev_out = (out_rgb8 && out_is_device) ? out_rgb8 : nullptr;
+    c->prev_stream = c->stream;
+    c->touched = false;
     c->last_mode = 0;
     if (async_applicable(c)) {
         if (int rc = run_async(c, K, full))
@@ -2098,8 +2181,10 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         if (int rc = run_wavefront(c, K, full, spp, max_depth))
             return rc;
         c->last_mode = 1;
-    } else if (pmode == 1 && pm1_wg == 2)
+    } else if (pmode == 1 && pm1_wg == 2) {
+        c->split_eff = 1;
         hipLaunchKernelGGL((pt::path_trace_kernel<0, false, 1, 2>), dim3((grid + 1) / 2), dim3(128), lds_main, c->stream, K);
+    }
     else if (pmode == 1)
         launch_trace<0, 1>(c, K, full, grid, lds_main);
     else if (pmode == 4)
@@ -2128,6 +2213,19 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     else
         launch_trace<2, 0>(c, K, full, grid, lds);
     HIP_TRY(c, hipGetLastError());
+    for (int i = 0; c->split_eff > 1 && i < c->split_eff; ++i) { // join: what follows on the context's stream follows every launch
+        HIP_TRY(c, hipEventRecord(c->split_join[i], c->aux_stream[i]));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_join[i], 0));
+    }
+    c->prev_split = 0;
+    if (c->split_eff > 1) {
+        c->prev_split = c->split_eff;
+    } else if (splittable && c->last_mode == 0) { // one launch on the stream: the point the next frame's launches may follow
+        if (!c->split_fork)
+            HIP_TRY(c, hipEventCreateWithFlags(&c->split_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->split_fork, c->stream));
+        c->prev_split = 1;
+    }
     if (timing)
         HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     if (tuning) {
@@ -2206,7 +2304,7 @@ int ptrt_post_frame(ptrt_ctx *c, const float *accum, const float *normal, const 
 }
 
 int ptrt_sync(ptrt_ctx *c) {
-    if (!ctx_live(c))
+    if (!ctx_live(c, false))
         return fail(c, PTRT_E_INVALID, "ptrt_sync: bad context");
     if (int rc = set_device(c))
         return rc;
@@ -2463,6 +2561,7 @@ int ptrt_kernel_ms_history(ptrt_ctx *c, float *out_ms, int max_n) {
 void *ptrt_device_buffer(ptrt_ctx *c, int kind) {
     if (!ctx_live(c))
         return nullptr;
+    c->escaped = true; // (the caller may read the context's buffers on streams of its own: frames no longer overlap)
     switch (kind) {
     case PTRT_BUF_ACCUM: return c->d_accum;
     case PTRT_BUF_NORMAL: return c->scaled() ? c->s_normal : c->d_normal;
@@ -2613,7 +2712,7 @@ int ptrt_get_stats(ptrt_ctx *c, ptrt_stats *out) {
 }
 
 int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
-    if (!ctx_live(c) || !name)
+    if (!ctx_live(c, false) || !name)
         return fail(c, PTRT_E_INVALID, "ptrt_set_option: bad argument");
     const std::string n(name);
     if (n == "count_rays")
@@ -2643,7 +2742,13 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
     }
     else if (n == "time_kernels") // 0: no start / stop events around the trace kernel (two driver calls per frame; ptrt_kernel_ms_history then has nothing)
         c->time_kernels = value ? 1 : 0;
-    else if (n == "tlas_rounds") // PMODE 3 shadow rays: one TLAS leaf per ray and fill instead of all of them (A/B, tests)
+    else if (n == "pipeline") // 1 (default): consecutive frames may overlap on the device when that is safe (ptrt_render); 0: never
+        c->pipeline = value ? 1 : 0;
+    else if (n == "split") { // tile rows of the frame dealt to that many concurrent launches of the megakernel (1 = one launch)
+        if (value < 1 || value > ptrt_ctx::MAX_SPLIT)
+            return fail(c, PTRT_E_INVALID, "split must be 1..%d", ptrt_ctx::MAX_SPLIT);
+        c->split = (int)value;
+    } else if (n == "tlas_rounds") // PMODE 3 shadow rays: one TLAS leaf per ray and fill instead of all of them (A/B, tests)
         c->tlas_rounds = value ? 1 : 0;
     else if (n == "pm1_wg") { // PMODE 1: one or two tiles per workgroup (0 = choose by the LDS budget; A/B, tests)
         if (value < 0 || value > 2)
@@ -2683,13 +2788,13 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
 
 // what ptrt_set_option set, plus read-only facts about the last ptrt_render (so that a measurement can say what ran)
 int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
-    if (!ctx_live(c) || !name || !value)
+    if (!ctx_live(c, false) || !name || !value)
         return fail(c, PTRT_E_INVALID, "ptrt_get_option: bad argument");
     const std::string n(name);
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

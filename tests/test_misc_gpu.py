@@ -214,3 +214,58 @@ def test_full_size_frames_equal_the_oracle(P, O, blue_noise, scene, spp, frames)
     gpu, cpu = render_both(P, O, s, blue_noise, spp, 4, frames, threads=16)
     assert_frames_equal(gpu, cpu)
     s.close()
+
+
+@pytest.mark.parametrize("scene", ["cornell", "showcase"])
+def test_pipelined_frames_are_the_same_frames(P, scene):
+    """Consecutive frames into ALTERNATING device targets overlap on the device (ptrt_set_option "pipeline", the default: a
+    frame's launches follow the previous frame's launches of the same tile rows on auxiliary streams and do not wait for
+    the stream the caller sees).  Every frame -- RGB8, HDR image, generator states, ray counts -- equals the frame rendered
+    with the launches ordered behind the stream; an entry point that may touch device state (here: a generator reset, a
+    camera is not one), the same target twice, or a handed-out buffer pointer make a frame wait again."""
+    import torch
+    W, H = 640, 360
+    build = P.scenes.cornell if scene == "cornell" else (lambda s: P.scenes.showcase(s, segments=16))
+
+    def run(pipeline):
+        s = P.Scene(W, H)
+        build(s)
+        s.setPerfSamplesPerPixel(2)
+        s.setMaxBounceDepth(4)
+        s.setDenoiserEnabled(False)
+        s.setBloomEnabled(False)
+        s.initBlueNoise()
+        s.uploadToGPU()
+        s.set_option("count_rays", 1)
+        s.set_option("merged", 0)  # (no loop-shape sampling: it orders its frames behind the stream)
+        s.set_option("pipeline", pipeline)
+        tgt = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        frames, flags = [], []
+        for f in range(8):
+            if f == 5:
+                s.moveCamera((0.3, 0.1, 5.0))  # host state only: the next frame still overlaps
+            s.render_to_device(tgt[f & 1].data_ptr())
+            flags.append(s.get_option("pipelined"))
+            if f in (2, 7):  # (reading back in between would order everything: only here)
+                s.sync()
+                frames.append((tgt[f & 1].cpu().numpy().copy(), s.read(P.BUF_ACCUM), s.read(P.BUF_RNG), s.stats()))
+        # the same target twice: the second frame waits for the stream
+        s.render_to_device(tgt[1].data_ptr())
+        s.render_to_device(tgt[1].data_ptr())
+        same_target = s.get_option("pipelined")
+        s.reset_rng(P.DEFAULT_SEED)
+        s.render_to_device(tgt[0].data_ptr())
+        after_reset = s.get_option("pipelined")
+        s.close()
+        return frames, flags, same_target, after_reset
+
+    on, flags_on, same_on, reset_on = run(1)
+    off, flags_off, _, _ = run(0)
+    assert flags_off == [0] * 8 and same_on == 0 and reset_on == 0
+    # frame 0 waits (uploads came before it); from the second alternation on the frames overlap -- the read-back after
+    # frame 2 (a synchronising entry point) makes frame 3 wait once more
+    assert flags_on[0] == 0 and flags_on[1] == 1 and flags_on[2] == 1 and flags_on[3] == 0 and flags_on[4:] == [1, 1, 1, 1], flags_on
+    for (a_rgb, a_acc, a_rng, a_st), (b_rgb, b_acc, b_rng, b_st) in zip(on, off):
+        assert np.array_equal(a_rgb, b_rgb) and np.array_equal(a_acc.view(np.uint32), b_acc.view(np.uint32))
+        assert np.array_equal(a_rng, b_rng) and a_st == b_st
+    assert on[1][0].any()

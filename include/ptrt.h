@@ -488,7 +488,9 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         of 8x8 tiles, to `split` launches on auxiliary streams of the context; launch i follows launch i of the
  *                         previous frame (the same pixels) and the frame is joined onto the context's stream by events, so
  *                         WHAT FOLLOWS ptrt_render ON THE STREAM STILL FOLLOWS THE FRAME -- but the frame itself may start while
- *                         the previous frame's last waves drain and while work enqueued EARLIER on the stream still runs
+ *                         the previous frame's last waves drain and while what the caller enqueued on the stream AFTER the
+ *                         previous ptrt_render call still runs; it waits for everything that was on the stream when that
+ *                         previous call was made, i.e. for the consumers of every frame but the last
  *                         (Cornell 1080p 1.81 -> 1.68 ms, showcase 3.85 -> 3.57).  Only when nothing else can have a claim on
  *                         what the frame reads or overwrites: a DEVICE target other than the previous frame's (double buffering:
  *                         whatever consumes the previous target on the stream is still entitled to it), no denoiser / bloom /

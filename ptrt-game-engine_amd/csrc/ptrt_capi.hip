@@ -185,6 +185,8 @@ struct ptrt_ctx {
     hipStream_t prev_stream = nullptr;
     int prev_split = 0;
     bool pipelined_last = false;  // the last frame's launches did not wait for the stream (ptrt_get_option "pipelined")
+    hipEvent_t head_ev[2] = {nullptr, nullptr}; // the stream's head at the start of the last two ptrt_render calls
+    unsigned head_n = 0;
     int tlas_rounds = 0; // option (A/B, tests): PMODE 3 shadow rays take one TLAS leaf per fill, as scenes with > 1024 meshes do
     int stage = 7; // PMODE 1, shading inputs staged in LDS: 0 none, else jitter table + blue noise, | 1 lights, | 2 materials
     int lds_nodes = 0; // option: PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels (measured slower: DESIGN.md 3.1)
@@ -1170,6 +1172,9 @@ void ptrt_destroy(ptrt_ctx *c) {
     }
     if (c->split_fork)
         (void)hipEventDestroy(c->split_fork);
+    for (hipEvent_t e : c->head_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     free_scene(c);
     dfree(c->d_materials);
     dfree(c->d_lights);
@@ -2145,6 +2150,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // a DEVICE target other than the previous frame's (whatever consumes that one on the stream is still entitled to it).
     // A frame that cannot overlap is ONE launch on the context's stream, as ever (concurrent launches of one frame buy
     // nothing: Cornell 1.85 vs 1.82 ms) -- followed by an event the next frame's launches wait for if that one can.
+    // What an overlapping frame DOES wait for, besides its predecessor's launches: everything that was on the stream when the
+    // PREVIOUS ptrt_render was called -- the consumers of the frame before that one, whose target a double-buffering caller
+    // hands in again now.  (head_ev alternates: [head_n & 1] is recorded now, the other one is the previous call's.)
     c->split_eff = 1;
     c->pipelined_last = false;
     const int n_split = c->split < ptrt_ctx::MAX_SPLIT ? c->split : ptrt_ctx::MAX_SPLIT;
@@ -2162,12 +2170,22 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                     HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking));
                     HIP_TRY(c, hipEventCreateWithFlags(&c->split_join[i], hipEventDisableTiming));
                 }
-            if (c->prev_split != n_split) // the previous frame was one launch on the stream: follow it (and only it)
-                for (int i = 0; i < n_split; ++i)
+            for (int i = 0; i < n_split; ++i) {
+                if (c->prev_split != n_split) // the previous frame was one launch on the stream: follow it (and only it)
                     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream[i], c->split_fork, 0));
+                if (c->head_ev[(c->head_n + 1) & 1])
+                    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream[i], c->head_ev[(c->head_n + 1) & 1], 0));
+            }
             c->split_eff = n_split;
             c->pipelined_last = true;
         }
+    }
+    if (splittable) { // the stream's head at this call, for the NEXT frame
+        hipEvent_t &he = c->head_ev[c->head_n & 1];
+        if (!he)
+            HIP_TRY(c, hipEventCreateWithFlags(&he, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(he, c->stream));
+        ++c->head_n;
     }
     c->prev_out = (out_rgb8 && out_is_device) ? out_rgb8 : nullptr;
     c->prev_stream = c->stream;

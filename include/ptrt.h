@@ -496,8 +496,8 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         whatever consumes the previous target on the stream is still entitled to it), no denoiser / bloom /
  *                         reduced size, no ptrt_* call since the previous ptrt_render other than the host-only ones
  *                         (ptrt_set_camera / _sky / _option / _prev_view_proj, ptrt_get_option, ptrt_sync, ptrt_last_error,
- *                         ptrt_set_bloom(0)), no pointer from ptrt_device_buffer in the caller's hands, not behind a real TLAS,
- *                         not while the loop shape is being sampled or the stream captured.  Any other frame is ONE launch
+ *                         ptrt_set_bloom(0)), no pointer from ptrt_device_buffer in the caller's hands, not while the loop shape is
+ *                         being sampled or the stream captured.  Any other frame is ONE launch
  *                         ordered behind the stream, as with pipeline = 0.  ptrt_get_option "pipelined" says which the last one was.
  *   tlas_rounds 0|1       real TLAS: shadow rays take one TLAS leaf per fill of the pair list (what > 1024 meshes use) instead of all
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)

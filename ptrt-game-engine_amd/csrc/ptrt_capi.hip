@@ -179,6 +179,7 @@ struct ptrt_ctx {
     static constexpr int MAX_SPLIT = 4;
     hipStream_t aux_stream[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t split_fork = nullptr, split_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
+    bool heads_fresh = false;     // PMODE 3: the TLAS-leaf-order heads were gathered since the last touching entry point
     bool touched = true;          // an entry point that may enqueue device work ran since the last ptrt_render (ctx_live)
     bool escaped = false;         // ptrt_device_buffer handed out pointers into the context's buffers
     void *prev_out = nullptr;     // the previous frame's device target
@@ -788,8 +789,10 @@ int run_async(ptrt_ctx *c, const pt::KParams &K, bool full) {
 bool ctx_live(ptrt_ctx *c, bool device_work = true) {
     std::lock_guard<std::mutex> lock(g_live_mutex);
     const bool live = c && g_live.count(c);
-    if (live && device_work)
+    if (live && device_work) {
         c->touched = true;
+        c->heads_fresh = false;
+    }
     return live;
 }
 
@@ -2076,7 +2079,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     if (c->merged < 0 && pmode == 4)
         K.steal = 0; // (the merged loop is at its best without shadow-ray subtree stealing: 3.98 vs 4.17 ms on the showcase frame)
     const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
-    if (pmode == 3) { // (outside the timed kernel: a 136-thread copy)
+    // (the heads only change with the mesh records: a frame since whose predecessor no entry point touched the device keeps them)
+    if (pmode == 3 && (c->touched || !c->heads_fresh)) { // (outside the timed kernel: a 136-thread copy)
+        c->heads_fresh = true;
         hipLaunchKernelGGL(pt::gather_tlas_heads_kernel, dim3((c->n_tlas_index + 63) / 64), dim3(64), 0, c->stream,
                            c->d_mesh_recs, c->d_inst_pre, c->d_tlas_mesh_ids, c->n_tlas_index, c->d_tlas_heads,
                            c->inst_pre_ok ? 1 : 0);
@@ -2145,8 +2150,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // its stream; it need not wait for the stream the caller sees, onto which every frame is joined by events.  That is safe
     // only while nothing else has a claim on what it reads or overwrites: no entry point that could have enqueued device work
     // or changed device data since the last frame (`touched`, set by ctx_live), no post chain reading the HDR image on the
-    // stream, no pointers into the context's buffers in the caller's hands, no loop-shape sampling (it times launches), no
-    // per-frame preparation on the stream (PMODE 3's head gather), not while the caller records the stream into a graph, and
+    // stream, no pointers into the context's buffers in the caller's hands, no loop-shape sampling (it times launches), not
+    // while the caller records the stream into a graph, and
     // a DEVICE target other than the previous frame's (whatever consumes that one on the stream is still entitled to it).
     // A frame that cannot overlap is ONE launch on the context's stream, as ever (concurrent launches of one frame buy
     // nothing: Cornell 1.85 vs 1.82 ms) -- followed by an event the next frame's launches wait for if that one can.
@@ -2158,7 +2163,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const int n_split = c->split < ptrt_ctx::MAX_SPLIT ? c->split : ptrt_ctx::MAX_SPLIT;
     const bool splittable = c->pipeline && n_split > 1 && tiles_y >= 2 * n_split && !async_applicable(c) &&
                             !wavefront_applicable(c, spp, max_depth) && !(pmode == 1 && pm1_wg == 2) &&
-                            !(pmode == 2 && c->lds_nodes && c->stack_entries > 0) && pmode != 3;
+                            !(pmode == 2 && c->lds_nodes && c->stack_entries > 0);
     if (splittable && !c->touched && !c->escaped && !tuning && !(denoise || bloom || scaled) && out_rgb8 && out_is_device &&
         out_rgb8 != c->prev_out && c->prev_stream == c->stream && c->prev_split > 0) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

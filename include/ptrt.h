@@ -493,8 +493,9 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         previous call was made, i.e. for the consumers of every frame but the last
  *                         (Cornell 1080p 1.81 -> 1.68 ms, showcase 3.85 -> 3.57).  Only when nothing else can have a claim on
  *                         what the frame reads or overwrites: a DEVICE target other than the previous frame's (double buffering:
- *                         whatever consumes the previous target on the stream is still entitled to it), no denoiser / bloom /
- *                         reduced size, no ptrt_* call since the previous ptrt_render other than the host-only ones
+ *                         whatever consumes the previous target on the stream is still entitled to it), no reduced render
+ *                         size (with the denoiser or bloom the context keeps two sets of HDR image and G-buffers and
+ *                         alternates, so that a frame's post chain and the next frame's trace do not share one), no ptrt_* call since the previous ptrt_render other than the host-only ones
  *                         (ptrt_set_camera / _sky / _option / _prev_view_proj, ptrt_get_option, ptrt_sync, ptrt_last_error,
  *                         ptrt_set_bloom(0)), no pointer from ptrt_device_buffer in the caller's hands, not while the loop shape is
  *                         being sampled or the stream captured.  Any other frame is ONE launch

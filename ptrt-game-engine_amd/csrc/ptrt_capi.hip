@@ -55,6 +55,10 @@ struct ptrt_ctx {
     uint32_t *d_rng = nullptr;
     float *d_accum = nullptr, *d_normal = nullptr, *d_depth = nullptr;
     int *d_object_id = nullptr;
+    // second set of the four, allocated when frames with a post chain overlap (ptrt_render "pipeline"): the trace of frame
+    // N + 1 writes one set while the denoiser / bloom of frame N still reads the other; d_* is always the latest frame's
+    float *alt_accum = nullptr, *alt_normal = nullptr, *alt_depth = nullptr;
+    int *alt_object_id = nullptr;
     unsigned char *d_rgb8 = nullptr;
     unsigned char *last_rgb8 = nullptr; // where the last frame's RGB8 went
     void *last_frame_target = nullptr;  // ... or the caller's frame it was written into (PTRT_OUT_DEVICE_FRAME)
@@ -1186,6 +1190,10 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_normal);
     dfree(c->d_depth);
     dfree(c->d_object_id);
+    dfree(c->alt_accum);
+    dfree(c->alt_normal);
+    dfree(c->alt_depth);
+    dfree(c->alt_object_id);
     dfree(c->d_rgb8);
     dfree(c->d_counters);
     dfree(c->wf_st);
@@ -1967,7 +1975,6 @@ int ptrt_set_bloom(ptrt_ctx *c, int enabled) {
         c->bloom_on = 0; // the mips stay allocated, as in the reference
         return PTRT_OK;
     }
-    c->touched = true;
     if (c->rows != c->H || c->y0 != 0)
         return fail(c, PTRT_E_INVALID, "ptrt_set_bloom: bloom needs a full-frame context (its blur reads across band "
                                        "borders); apply it on the presenting rank instead");
@@ -1980,8 +1987,10 @@ int ptrt_set_bloom(ptrt_ctx *c, int enabled) {
     for (int i = 0; i < 6; ++i) { // scene.cuh:809-822: sized from the FULL frame
         mw /= 2;
         mh /= 2;
-        if (!c->bl_mip[i])
+        if (!c->bl_mip[i]) {
+            c->touched = true; // (the first time only: a caller that sets the flag every frame keeps its frames overlapping)
             HIP_TRY(c, hipMalloc((void **)&c->bl_mip[i], (size_t)mw * mh * 12));
+        }
     }
     c->bloom_on = 1;
     return PTRT_OK;
@@ -2149,8 +2158,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // rows) as launch i of frame N and nothing else of that frame, so it only has to follow THAT launch, which it does on
     // its stream; it need not wait for the stream the caller sees, onto which every frame is joined by events.  That is safe
     // only while nothing else has a claim on what it reads or overwrites: no entry point that could have enqueued device work
-    // or changed device data since the last frame (`touched`, set by ctx_live), no post chain reading the HDR image on the
-    // stream, no pointers into the context's buffers in the caller's hands, no loop-shape sampling (it times launches), not
+    // or changed device data since the last frame (`touched`, set by ctx_live), no reduced render size (a post chain at full
+    // size gets a second set of HDR image and G-buffers: below), no pointers into the context's buffers in the caller's hands, no loop-shape sampling (it times launches), not
     // while the caller records the stream into a graph, and
     // a DEVICE target other than the previous frame's (whatever consumes that one on the stream is still entitled to it).
     // A frame that cannot overlap is ONE launch on the context's stream, as ever (concurrent launches of one frame buy
@@ -2164,7 +2173,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const bool splittable = c->pipeline && n_split > 1 && tiles_y >= 2 * n_split && !async_applicable(c) &&
                             !wavefront_applicable(c, spp, max_depth) && !(pmode == 1 && pm1_wg == 2) &&
                             !(pmode == 2 && c->lds_nodes && c->stack_entries > 0);
-    if (splittable && !c->touched && !c->escaped && !tuning && !(denoise || bloom || scaled) && out_rgb8 && out_is_device &&
+    if (splittable && !c->touched && !c->escaped && !tuning && !scaled && out_rgb8 && out_is_device &&
         out_rgb8 != c->prev_out && c->prev_stream == c->stream && c->prev_split > 0) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess)
@@ -2180,6 +2189,24 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream[i], c->split_fork, 0));
                 if (c->head_ev[(c->head_n + 1) & 1])
                     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream[i], c->head_ev[(c->head_n + 1) & 1], 0));
+            }
+            if (denoise || bloom) {
+                // the post chain of the previous frame may still be reading the HDR image and the G-buffers on the stream:
+                // this frame's trace writes the OTHER set (its own post chain, enqueued behind the join, reads that one)
+                if (!c->alt_accum) {
+                    HIP_TRY(c, hipMalloc((void **)&c->alt_accum, c->npix * 3 * sizeof(float)));
+                    HIP_TRY(c, hipMalloc((void **)&c->alt_normal, c->npix * 3 * sizeof(float)));
+                    HIP_TRY(c, hipMalloc((void **)&c->alt_depth, c->npix * sizeof(float)));
+                    HIP_TRY(c, hipMalloc((void **)&c->alt_object_id, c->npix * sizeof(int)));
+                }
+                std::swap(c->d_accum, c->alt_accum);
+                std::swap(c->d_normal, c->alt_normal);
+                std::swap(c->d_depth, c->alt_depth);
+                std::swap(c->d_object_id, c->alt_object_id);
+                K.accum = c->d_accum;
+                K.normal = c->d_normal;
+                K.depth = c->d_depth;
+                K.object_id = c->d_object_id;
             }
             c->split_eff = n_split;
             c->pipelined_last = true;

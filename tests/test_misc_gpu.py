@@ -216,7 +216,7 @@ def test_full_size_frames_equal_the_oracle(P, O, blue_noise, scene, spp, frames)
     s.close()
 
 
-@pytest.mark.parametrize("scene", ["cornell", "showcase"])
+@pytest.mark.parametrize("scene", ["cornell", "showcase", "cornell+post"])
 def test_pipelined_frames_are_the_same_frames(P, scene):
     """Consecutive frames into ALTERNATING device targets overlap on the device (ptrt_set_option "pipeline", the default: a
     frame's launches follow the previous frame's launches of the same tile rows on auxiliary streams and do not wait for
@@ -225,15 +225,16 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
     camera is not one), the same target twice, or a handed-out buffer pointer make a frame wait again."""
     import torch
     W, H = 640, 360
-    build = P.scenes.cornell if scene == "cornell" else (lambda s: P.scenes.showcase(s, segments=16))
+    post = scene.endswith("+post")  # denoiser + bloom: the trace alternates between two sets of HDR image and G-buffers
+    build = P.scenes.cornell if scene.startswith("cornell") else (lambda s: P.scenes.showcase(s, segments=16))
 
     def run(pipeline):
         s = P.Scene(W, H)
         build(s)
         s.setPerfSamplesPerPixel(2)
         s.setMaxBounceDepth(4)
-        s.setDenoiserEnabled(False)
-        s.setBloomEnabled(False)
+        s.setDenoiserEnabled(post)
+        s.setBloomEnabled(post)
         s.initBlueNoise()
         s.uploadToGPU()
         s.set_option("count_rays", 1)

@@ -1432,6 +1432,7 @@ namespace pt {
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 3
 #endif
+
 // Waves per SIMD a variant is built for (= its register budget: 512 / waves, in steps of 8).  PMODE 1 with the simple
 // materials -- a whole small scene in 7.5 KB of LDS, no traversal stacks -- runs five (96 VGPRs; the Cornell kernel then
 // spills 22 registers, 88 B per lane, and is still 4 % faster: 2.233 -> 2.150 ms).  Its FULL variant would spill 168 B per
@@ -1465,7 +1466,7 @@ PT_DEV const KParams &kparams(kparams_ptr p) {
     asm volatile("" : "+s"(p));
     return *(const KParams *)p;
 }
-template <int GEOM, bool FULL, int PMODE, int WG = 1>
+template <int GEOM, bool FULL, int PMODE, int WG = 1, bool STREAM = false>
 __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_per_simd(PMODE, FULL, WG), 8))) void path_trace_kernel(const KParams Kin) {
     // The parameters are read where they are used, through the kernarg segment itself (scalar loads that hit the constant
     // cache), not out of the by-value copy: ~110 dwords of pointers, camera and options held in SGPRs across the persistent
@@ -1539,6 +1540,10 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         }
         __syncthreads();
     }
+    // STREAM (one-wave workgroups; instantiated for PMODE 1): the launch is a grid of PERSISTENT waves and a lane that has
+    // finished its pixel takes the next one of the launch -- [R] in the loop below -- instead of idling until the slowest
+    // pixel of its 8x8 tile is done (tools/trav_stats.py: 18 % of the lane-iterations of a 1080p Cornell frame).
+    static_assert(!STREAM || WG == 1, "lane refill: one-wave workgroups");
     const int tile = WG > 1 ? blockIdx.x * WG + wave : blockIdx.x;
     // (a larger workgroup's last tiles may not exist: such a wave takes part in the staging and the barrier with a tile
     // outside the frame -- `inside` is false for all its lanes -- and leaves before the loop)
@@ -1555,18 +1560,23 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     // compiler from hoisting them back into the loop's live set), the ray counters are wave totals in scalar registers.
     // (The running sum of the samples was tried in the pixel's own accum words, read-modify-write at the end of a
     // sample: three registers fewer, but a dependent global load in most iterations -- Cornell 2.40 -> 2.54 ms.)
+    int pxy = -1; // STREAM: the lane's pixel, x | local row << 16; -1: none
     auto px = [&]() {
+        if (STREAM)
+            return pxy & 0xffff;
         int l = lane;
         asm volatile("" : "+v"(l));
         return tx * 8 + (l & 7);
     };
     auto pyl = [&]() {
+        if (STREAM)
+            return pxy >> 16;
         int l = lane;
         asm volatile("" : "+v"(l));
         return ty * 8 + (l >> 3);
     };
     auto pidx = [&](int width) { return (size_t)pyl() * width + px(); };
-    const bool inside = (px() < K.width) && (pyl() < K.rows);
+    const bool inside = !STREAM && (px() < K.width) && (pyl() < K.rows);
     // PMODE 1 (a scene small enough for its triangles to sit in LDS): what the shading phases would otherwise fetch from
     // global memory in every iteration is staged too -- the jitter table and the lane's blue-noise value for [A], the light
     // records for [C], the material records by mesh order; [A], [C], [C2] and [E] then read no global memory.  Worth 2 %
@@ -1581,7 +1591,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             float4 *lights = const_cast<float4 *>(PL.lights), *mats = const_cast<float4 *>(PL.mats);
             if (threadIdx.x < 16)
                 jit[threadIdx.x] = taa_table_entry(threadIdx.x);
-            {
+            if (!STREAM) { // (STREAM: a lane's entry follows its pixel, [R])
                 const int x0 = px(), y0 = global_row(pyl(), K.y0, K.il_period, K.il_phase);
                 bn[lane] = K.blue_noise[(y0 & 63) * 64 + (x0 & 63)];
             }
@@ -1626,7 +1636,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         wave_sync();
     }
 
-    int s = inside ? 0 : K.spp;
+    int s = inside ? 0 : K.spp; // (STREAM: no lane has a pixel yet)
     int bounce = 0;
     bool fresh = true;
     f3 ro = mk3(0.0f), rd = mk3(0.0f);
@@ -1640,7 +1650,112 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     CycleAcc cyc;
     PL.cyc = &cyc;
     const unsigned long long t_kernel = TS_NOW();
+    // STREAM: the launch's tiles are numbered 0 .. n_tiles - 1 and handed out by tickets (K.queue[0]; one atomic per tile, the
+    // next ticket is drawn when the current tile is opened, so its latency hides behind that tile's work).  Wave-uniform:
+    // (A wave's FIRST tile is its own number -- no ticket, no burst of thousands of atomics on one address before anything
+    // runs; ticket k is tile gridDim.x + k.)
+    int q_org = 0, q_next = 64;    // the tile being handed out (x0 | local y0 << 16) and the next of its 64 pixels
+    uint32_t q_ticket = blockIdx.x; // lane 0: the tile drawn ahead
+    bool q_first = true;
+    bool q_open = STREAM;
+    uint32_t n_px = 0;             // pixels this wave took (counters)
     for (;;) {
+        if (STREAM) {
+            // ---- [R] lanes without work: write the finished pixel out, take the next one.  Which lane renders a pixel
+            // changes nothing in it: generator state, samples and sums are the pixel's own.
+            const KParams &KR = kparams(kp0);
+            const unsigned long long t_r = TS_NOW();
+            const bool idle = (s >= KR.spp) && !(MERGED && pending);
+            if (__builtin_amdgcn_ballot_w64(idle && (pxy >= 0 || q_open))) {
+                // Order matters for what the wave waits for: the new pixel is chosen FIRST and its blue-noise entry requested
+                // before anything else is in flight, so that the one wait of this block (the entry goes into the lane's LDS
+                // slot, [A] reads it at once) is for that load alone -- not for the nine stores of the finished pixel and
+                // the six loads of the new generator state behind it, which nothing needs before [C].
+                const int old = idle ? pxy : -1;
+                int got = -1;
+                while (q_open) {
+                    const bool wants = idle && got < 0;
+                    const unsigned long long want = __builtin_amdgcn_ballot_w64(wants);
+                    if (!want)
+                        break;
+                    if (q_next == 64) { // open the next tile
+                        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_ticket) + (q_first ? 0u : gridDim.x);
+                        q_first = false;
+                        if (t >= (uint32_t)KR.n_tiles) {
+                            q_open = false;
+                            break;
+                        }
+                        if (lane == 0) // (-amdgpu-atomic-optimizer-strategy=None: the result is not needed before the next tile)
+                            q_ticket = atomicAdd(KR.queue, 1u);
+                        const int trow = (int)t / KR.tiles_x, tcol = (int)t - trow * KR.tiles_x;
+                        q_org = (tcol * 8) | ((KR.split_n > 1 ? trow * KR.split_n + KR.split_i : trow) * 8) << 16;
+                        q_next = 0;
+                    }
+                    const int rank = lane_prefix(want), avail = 64 - q_next, asked = __builtin_popcountll(want);
+                    if (wants && rank < avail) {
+                        const int pix = q_next + rank;
+                        const int x = (q_org & 0xffff) + (pix & 7), yl = (q_org >> 16) + (pix >> 3);
+                        if (x < KR.width && yl < KR.rows) { // (else: the lane asks again in the next round)
+                            got = x | (yl << 16);
+                        }
+                    }
+                    n_px += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wants && got >= 0));
+                    q_next += asked < avail ? asked : avail;
+                }
+                // (the finished pixel's state moves to spare registers and is stored LAST: nothing waits for stores then)
+                const Rng rng_old = rng;
+                const f3 avg_old = avg_color;
+                if (got >= 0) {
+                    float2 bnv = make_float2(0.0f, 0.0f);
+                    if (STAGED) { // (no memory operation inside the loop above, none conditional here: the compiler's
+                                  // wait-count pass is flow-insensitive and would wait for everything in flight)
+                        const int gy = global_row(got >> 16, KR.y0, KR.il_period, KR.il_phase);
+                        bnv = KR.blue_noise[(gy & 63) * 64 + (got & 63)];
+                    }
+                    // (one 32-bit pixel index against six scalar plane bases: no 64-bit address arithmetic per plane)
+                    const uint32_t idx = (uint32_t)(got >> 16) * (uint32_t)KR.width + (uint32_t)(got & 0xffff);
+                    __builtin_assume(idx < (1u << 27));
+                    const size_t npix = KR.rng_plane;
+                    rng.d = (KR.rng)[idx];
+                    rng.v0 = (KR.rng + npix)[idx];
+                    rng.v1 = (KR.rng + 2 * npix)[idx];
+                    rng.v2 = (KR.rng + 3 * npix)[idx];
+                    rng.v3 = (KR.rng + 4 * npix)[idx];
+                    rng.v4 = (KR.rng + 5 * npix)[idx];
+                    if (STAGED) {
+                        asm volatile("" ::"v"(bnv.x), "v"(bnv.y)); // (the entry has arrived, whichever way the next branch goes)
+                        if (jit_lds)
+                            const_cast<float2 *>(PL.bn)[lane] = bnv;
+                    }
+                    pxy = got;
+                    avg_color = mk3(0.0f);
+                    s = 0;
+                    fresh = true;
+                } else if (old >= 0) {
+                    pxy = -1;
+                }
+                if (old >= 0) {
+                    const uint32_t idx = (uint32_t)(old >> 16) * (uint32_t)KR.width + (uint32_t)(old & 0xffff);
+                    __builtin_assume(idx < (1u << 27));
+                    const size_t npix = KR.rng_plane;
+                    (KR.rng)[idx] = rng_old.d;
+                    (KR.rng + npix)[idx] = rng_old.v0;
+                    (KR.rng + 2 * npix)[idx] = rng_old.v1;
+                    (KR.rng + 3 * npix)[idx] = rng_old.v2;
+                    (KR.rng + 4 * npix)[idx] = rng_old.v3;
+                    (KR.rng + 5 * npix)[idx] = rng_old.v4;
+                    // (a power-of-two sample count divides exactly by multiplication: the same bits as the division)
+                    const float n = (float)KR.spp;
+                    const f3 out = (KR.spp & (KR.spp - 1)) == 0 ? avg_old * (1.0f / n) : avg_old / n;
+                    const uint32_t i3 = idx * 3u;
+                    KR.accum[i3 + 0] = out.x;
+                    KR.accum[i3 + 1] = out.y;
+                    KR.accum[i3 + 2] = out.z;
+                }
+            }
+            if (PMODE == 1)
+                TS_ADD(15, t_r);
+        }
         const KParams &KL = kparams(kp0);
         if (!__builtin_amdgcn_ballot_w64(s < KL.spp || (MERGED && pending)))
             break;
@@ -2008,6 +2123,30 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         // (tonemap_kernel fused, below: RGB8, rows flipped within the tile (scene.cuh:2013-2015); skipped -- wave-uniform --
         // when a denoiser / bloom / up-scale stage follows and tonemaps its own result)
     }
+    if (STREAM) { // the pixels left in [R]; the image is tonemapped by tonemap_tiles_kernel behind this launch
+        if (KZ.counters) {
+            if (LDS_COUNT) {
+                wave_sync();
+                const unsigned long long t = lds_count[0];
+                n_ext = (uint32_t)t;
+                n_shadow = (uint32_t)(t >> 32);
+                n_zero = (uint32_t)lds_count[1];
+            }
+            if (lane == 0) { // (a slot per wave and launch: concurrent launches of a split frame do not share one)
+                unsigned long long *w = KZ.counters + ((size_t)blockIdx.x * (KZ.split_n > 1 ? KZ.split_n : 1) + KZ.split_i) * COUNTER_WORDS;
+                w[0] += (unsigned long long)n_ext;
+                w[1] += (unsigned long long)n_shadow;
+                w[2] += (unsigned long long)n_px * (unsigned long long)KZ.spp;
+                w[3] += (unsigned long long)n_zero;
+            }
+        }
+        // the last wave out leaves the queue as it found it (every other wave has drawn its last ticket)
+        if (lane == 0 && atomicAdd(KZ.queue + 1, 1u) == gridDim.x - 1u) {
+            atomicExch(KZ.queue, 0u);
+            atomicExch(KZ.queue + 1, 0u);
+        }
+        return;
+    }
     if (KZ.rgb8) {
         // A tile row is 8 pixels = 24 contiguous bytes of the bottom-up image.  Full tiles of a frame whose rows are
         // dword-aligned leave as six dwords per row: lane c < 6 of a row takes the (at most two) pixels its dword
@@ -2056,6 +2195,38 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             w[2] += (unsigned long long)c;
             w[3] += (unsigned long long)n_zero;
         }
+    }
+}
+
+// Lane refill (path_trace_kernel<.., STREAM = true>): the fused tonemap as a pass of its own behind the launch (same tiles, same mapping, same
+// bytes): a persistent wave's pixels are not a tile's, so there is no tile epilogue to put it in.  One wave per 8x8 tile.
+__global__ __launch_bounds__(64) void tonemap_tiles_kernel(const KParams K) {
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const int tx = tile % K.tiles_x;
+    const int ty = K.split_n > 1 ? (tile / K.tiles_x) * K.split_n + K.split_i : tile / K.tiles_x;
+    const int x = tx * 8 + (lane & 7), yl = ty * 8 + (lane >> 3);
+    const bool inside = x < K.width && yl < K.rows;
+    unsigned char r8 = 0, g8 = 0, b8 = 0;
+    if (inside) {
+        const size_t idx = (size_t)yl * K.width + x;
+        tonemap_pixel(mk3(K.accum[idx * 3 + 0], K.accum[idx * 3 + 1], K.accum[idx * 3 + 2]), r8, g8, b8);
+    }
+    const bool full_tile = (tx * 8 + 8 <= K.width) && (ty * 8 + 8 <= K.rows) && (K.width % 4 == 0) && (((size_t)K.rgb8 & 3u) == 0u);
+    if (full_tile) { // six dwords per tile row (see path_trace_kernel's epilogue)
+        const uint32_t pix = (uint32_t)r8 | ((uint32_t)g8 << 8) | ((uint32_t)b8 << 16);
+        const int c = lane & 7, first = (4 * c) / 3;
+        const int src = (lane & ~7) | (first < 7 ? first : 7), src1 = (lane & ~7) | (first + 1 < 7 ? first + 1 : 7);
+        const unsigned long long two = (unsigned long long)(uint32_t)__shfl((int)pix, src) |
+                                       ((unsigned long long)(uint32_t)__shfl((int)pix, src1) << 24);
+        if (c < 6) {
+            uint32_t *row = (uint32_t *)(K.rgb8 + ((size_t)rgb8_row(K, yl) * K.width + (size_t)tx * 8) * 3);
+            row[c] = (uint32_t)(two >> (8 * ((4 * c) % 3)));
+        }
+    } else if (inside) {
+        const size_t o = ((size_t)rgb8_row(K, yl) * K.width + x) * 3;
+        K.rgb8[o + 0] = r8;
+        K.rgb8[o + 1] = g8;
+        K.rgb8[o + 2] = b8;
     }
 }
 

@@ -165,6 +165,12 @@ struct ptrt_ctx {
     // asynchronous-lane megakernel (pt_async.hip.h)
     int async_lanes = 0, shade_min = 32, as_leaf_min = 24; // options
     uint32_t *as_cursor = nullptr;
+    // Lane refill (PMODE 1, path_trace_kernel<.., STREAM = true>): option "refill" 0 never, 1 (default) where it was measured to
+    // pay -- frames that overlap their predecessor, simple materials, no post chain, spp * bounces >= 16 --, 2 wherever PMODE 1 runs (tests)
+    int refill = 1;
+    bool refill_eff = false;         // ... the last frame
+    unsigned int *d_queue = nullptr; // {ticket, waves out} per launch lane: [0] the stream, [1 + i] auxiliary stream i
+    int persist = 0, n_cus = 0;      // option "persist": persistent waves per CU (0 = the variant's occupancy)
     int as_blocks[2] = {0, 0}; // resident workgroups of the <false>/<true> kernel at as_lds bytes of LDS
     size_t as_lds = 0;
 
@@ -623,6 +629,23 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
         if (g <= 0)
             continue;
         hipStream_t st = n > 1 ? c->aux_stream[i] : c->stream;
+        if constexpr (PMODE == 1) {
+            if (c->refill_eff) {
+                // Lane refill: persistent waves -- as many as the chip holds at this variant's occupancy (option "persist":
+                // waves per CU) -- that draw the launch's tiles from a queue; the image is tonemapped by a pass behind them.
+                K.n_tiles = g;
+                K.queue = c->d_queue + 2 * (n > 1 ? 1 + i : 0); // (launches that share a queue are ordered: one stream each)
+                const int per_cu = c->persist > 0 ? c->persist : 4 * pt::waves_per_simd(PMODE, full, 1);
+                const int waves = std::min(g, c->n_cus * per_cu);
+                if (full)
+                    hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE, 1, true>), dim3(waves), dim3(64), lds, st, K);
+                else
+                    hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PMODE, 1, true>), dim3(waves), dim3(64), lds, st, K);
+                if (K.rgb8)
+                    hipLaunchKernelGGL(pt::tonemap_tiles_kernel, dim3(g), dim3(64), 0, st, K);
+                continue;
+            }
+        }
         if (full)
             hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE>), dim3(g), dim3(64), lds, st, K);
         else
@@ -1134,6 +1157,10 @@ int create_ctx(int full_w, int full_h, int tile_y0, int tile_rows, int il_period
     HIP_TRY(c, hipMalloc((void **)&c->d_rgb8, c->npix * 3));
     c->n_counter_slots = (size_t)((c->W + 7) / 8) * ((c->rows + 7) / 8); // one slot of pt::COUNTER_WORDS per 8x8-pixel workgroup
     c->n_counter_slots += 4; // the shade stage uses one slot per wave of a 256-thread grid (rounded up)
+    c->n_counter_slots += (size_t)ptrt_ctx::MAX_SPLIT * ((c->W + 7) / 8); // (lane refill: a slot per wave and launch of a split frame)
+    HIP_TRY(c, hipMalloc((void **)&c->d_queue, 2 * (1 + ptrt_ctx::MAX_SPLIT) * sizeof(unsigned int)));
+    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, 2 * (1 + ptrt_ctx::MAX_SPLIT) * sizeof(unsigned int), c->stream));
+    HIP_TRY(c, hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, c->device));
     HIP_TRY(c, hipMalloc((void **)&c->d_counters, c->n_counter_slots * pt::COUNTER_WORDS * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc((void **)&c->d_blue, PTRT_BLUE_NOISE_FLOATS * sizeof(float)));
     HIP_TRY(c, hipMemsetAsync(c->d_rng, 0, c->npix * 6 * sizeof(uint32_t), c->stream));
@@ -1196,6 +1223,7 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->alt_object_id);
     dfree(c->d_rgb8);
     dfree(c->d_counters);
+    dfree(c->d_queue);
     dfree(c->wf_st);
     dfree(c->wf_occ);
     dfree(c->wf_live);
@@ -2219,6 +2247,16 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         HIP_TRY(c, hipEventRecord(he, c->stream));
         ++c->head_n;
     }
+    // Lane refill (launch_trace): where it was measured to pay.  Overlapping 1080p Cornell frames 1.67 -> 1.62 ms, 8 bounces 2.12
+    // -> 1.88, 4K 6.65 -> 6.27; a frame alone on the chip ends in a long drain of half-empty persistent waves (1.81 -> 1.97),
+    // short pixels finish before the refill pays for itself (1 spp: 0.43 -> 0.61), and beside a post chain the persistent waves
+    // keep the chain's kernels waiting for a place on the chip (balanced preset 2.41 -> 2.50).
+    // (And a launch must hold at least two tiles per persistent wave -- 1280 x 720 measured even, smaller frames lose.)
+    const long per_launch = (long)grid / (c->split_eff > 1 ? c->split_eff : 1);
+    const long resident = (long)c->n_cus * (c->persist > 0 ? c->persist : 4 * pt::waves_per_simd(1, full, 1));
+    c->refill_eff = pmode == 1 && pm1_wg == 1 &&
+                    (c->refill == 2 || (c->refill == 1 && c->pipelined_last && !full && !denoise && !bloom &&
+                                        (long)spp * max_depth >= 16 && per_launch >= 2 * resident));
     c->prev_out = (out_rgb8 && out_is_device) ? out_rgb8 : nullptr;
     c->prev_stream = c->stream;
     c->touched = false;
@@ -2794,6 +2832,10 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->time_kernels = value ? 1 : 0;
     else if (n == "pipeline") // 1 (default): consecutive frames may overlap on the device when that is safe (ptrt_render); 0: never
         c->pipeline = value ? 1 : 0;
+    else if (n == "persist")
+        c->persist = value < 0 ? 0 : value;
+    else if (n == "refill")
+        c->refill = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "split") { // tile rows of the frame dealt to that many concurrent launches of the megakernel (1 = one launch)
         if (value < 1 || value > ptrt_ctx::MAX_SPLIT)
             return fail(c, PTRT_E_INVALID, "split must be 1..%d", ptrt_ctx::MAX_SPLIT);
@@ -2844,7 +2886,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"persist", c->persist}, {"refill", c->refill}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

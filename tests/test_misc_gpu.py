@@ -188,8 +188,9 @@ def test_full_size_traversal_variants_agree(P, scene):
     # merged=0: separate closest-hit and any-hit phases (PMODE 2) instead of one traversal per iteration (PMODE 4)
     # lds_nodes=1: four tiles per workgroup sharing an LDS copy of the mesh heads and of the BLAS top levels
     # pm1_wg=2: two tiles per workgroup sharing one LDS copy of a small scene, six waves per SIMD (PMODE 1)
+    # refill=2: PMODE 1 as persistent waves whose lanes draw the next pixel of the launch (the default for overlapping frames)
     # tlas_rounds=1: shadow rays behind a real TLAS take one leaf per fill (the path of scenes with more than 1024 meshes)
-    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1)):
+    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1), dict(refill=2)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):
             for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):
@@ -231,7 +232,7 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
     def run(pipeline):
         s = P.Scene(W, H)
         build(s)
-        s.setPerfSamplesPerPixel(2)
+        s.setPerfSamplesPerPixel(4 if scene == "cornell" else 2)  # (4 x 4: the overlapping Cornell frames run with lane refill)
         s.setMaxBounceDepth(4)
         s.setDenoiserEnabled(post)
         s.setBloomEnabled(post)
@@ -240,6 +241,7 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
         s.set_option("count_rays", 1)
         s.set_option("merged", 0)  # (no loop-shape sampling: it orders its frames behind the stream)
         s.set_option("pipeline", pipeline)
+        s.set_option("persist", 2)  # (512 persistent waves: this small frame then has enough tiles per wave for lane refill)
         tgt = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
         frames, flags = [], []
         for f in range(8):
@@ -247,6 +249,7 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
                 s.moveCamera((0.3, 0.1, 5.0))  # host state only: the next frame still overlaps
             s.render_to_device(tgt[f & 1].data_ptr())
             flags.append(s.get_option("pipelined"))
+            assert s.get_option("refilled") == (1 if scene == "cornell" and flags[-1] else 0)
             if f in (2, 7):  # (reading back in between would order everything: only here)
                 s.sync()
                 frames.append((tgt[f & 1].cpu().numpy().copy(), s.read(P.BUF_ACCUM), s.read(P.BUF_RNG), s.stats()))

@@ -22,6 +22,63 @@ def test_cornell_bit_exact(P, O, blue_noise, size, spp, depth, frames):
     s.close()
 
 
+@pytest.mark.parametrize("size,spp,depth,frames,kw", [
+    ((96, 72), 4, 4, 3, {}), ((61, 45), 2, 3, 2, {}), ((1, 1), 3, 4, 2, {}), ((250, 141), 2, 5, 2, {}),
+    ((64, 64), 2, 4, 2, dict(tile_y0=24, tile_rows=16)),          # a band context: the queue covers its rows only
+    ((96, 72), 2, 4, 2, dict(force_full=1)),                       # the all-materials variant
+    ((640, 360), 4, 4, 1, {})])                                    # more tiles than persistent waves would draw at once
+def test_cornell_lane_refill(P, O, blue_noise, size, spp, depth, frames, kw):
+    """ptrt_set_option "refill", 2: PMODE 1 as persistent waves whose lanes take the launch's next pixel when theirs is
+    finished (path_trace_kernel<.., STREAM = true> + tonemap_tiles_kernel) -- every buffer, generator state and ray count
+    as the oracle has them.  (By default only frames that overlap their predecessor run this way: test_misc_gpu.py.)"""
+    kw = dict(kw)
+    force_full = kw.pop("force_full", 0)
+    s = P.Scene(size[0], size[1], **kw)
+    P.scenes.cornell(s)
+    s.set_option("refill", 2)
+    s.set_option("persist", 1 if size == (640, 360) else 0)  # (256 waves for 3,600 tiles: every wave draws many tickets)
+    if force_full:
+        s.set_option("force_full", 1)
+    gpu, cpu = render_both(P, O, s, blue_noise, spp, depth, frames)
+    assert s.get_option("refilled") == 1
+    assert_frames_equal(gpu, cpu)
+    s.close()
+
+
+def test_lane_refill_over_interleaved_strips_and_into_a_shared_frame(P):
+    """Lane refill on contexts that own every third 8-row strip, each writing its rows straight into ONE device frame
+    (PTRT_OUT_DEVICE_FRAME): the frame and the strips' HDR rows are the full-frame context's (classic kernel)."""
+    import torch
+    W, H = 88, 52
+    def prep(s, refill):
+        P.scenes.cornell(s)
+        s.setPerfSamplesPerPixel(3)
+        s.setMaxBounceDepth(4)
+        s.setDenoiserEnabled(False)
+        s.setBloomEnabled(False)
+        s.initBlueNoise()
+        s.uploadToGPU()
+        s.set_option("refill", refill)
+    full = P.Scene(W, H)
+    prep(full, 0)
+    want = [full.render_to_host() for _ in range(2)]
+    want_acc = full.read(P.BUF_ACCUM).reshape(H, W, 3)
+    full.close()
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    farm = P.TileFarm(W, H, [0] * 3, strips=True)  # (the parts on the presenting GPU write straight into the frame)
+    for s in farm.scenes:
+        prep(s, 2)
+    for f in range(2):
+        farm.render_to_device(frame.data_ptr())
+        torch.cuda.synchronize()
+        assert all(s.get_option("refilled") == 1 for s in farm.scenes)
+        assert np.array_equal(frame.cpu().numpy(), want[f])
+    for r, s in enumerate(farm.scenes):
+        rows = [y for y in range(H) if (y // 8) % 3 == r]
+        assert np.array_equal(s.read(P.BUF_ACCUM).reshape(-1, W, 3).view(np.uint32), want_acc[rows].view(np.uint32))
+    farm.close()
+
+
 @pytest.mark.parametrize("force_geom", [1, 2])
 def test_cornell_general_traversal_variants(P, O, blue_noise, force_geom):
     """The general BLAS / general TLAS kernels must give the brute-force variant's bits."""

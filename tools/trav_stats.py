@@ -62,7 +62,7 @@ if cy[14]:  # instrumented build: where a wave's cycles go (s_memtime, summed ov
           f"everything else {100.0 - pct(12) - pct(13):.1f} %")
     if scene == "cornell":  # PMODE 1 has no queues: its build spends those slots on the shading phases
         print(f"   shading: [A] regenerate {pct(8):.1f} %, [C] surface + light sample {pct(9):.1f} %, [C2] BSDF of the light sample "
-              f"{pct(10):.1f} %, [E] scatter {pct(11):.1f} %")
+              f"{pct(10):.1f} %, [E] scatter {pct(11):.1f} %, [R] refill {pct(15):.1f} %")
     else:
         print(f"   inside: queue runs {pct(8):.1f} %, closest node loops {pct(9):.1f} %, closest leaf blocks {pct(10):.1f} %, "
               f"any-hit queue runs {pct(11):.1f} %")

@@ -500,6 +500,14 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         ptrt_set_bloom(0)), no pointer from ptrt_device_buffer in the caller's hands, not while the loop shape is
  *                         being sampled or the stream captured.  Any other frame is ONE launch
  *                         ordered behind the stream, as with pipeline = 0.  ptrt_get_option "pipelined" says which the last one was.
+ *   refill 0|1|2, persist N   PMODE 1, lane refill: the launch is a grid of persistent waves (`persist` per CU; 0 = what the
+ *                         kernel's occupancy holds) that draw the launch's 8x8 tiles from a queue, and a lane whose pixel is finished
+ *                         takes the next pixel instead of idling until the slowest pixel of its tile is done (18 % of the
+ *                         lane-iterations of a 1080p Cornell frame); the image is tonemapped by a pass behind the launch.  Which lane
+ *                         renders a pixel changes nothing in it: same bits.  1 (default): where it was measured to pay -- frames that
+ *                         overlap their predecessor ("pipeline"), simple materials, no post chain, spp x bounces >= 16, at least two
+ *                         tiles per persistent wave (1080p 4 spp 4 bounces 1.67 -> 1.63 ms, 8 bounces 2.12 -> 1.89, 4K 6.65 -> 6.27);
+ *                         2: wherever PMODE 1 runs; 0: never.  ptrt_get_option "refilled" says what the last frame did.
  *   tlas_rounds 0|1       real TLAS: shadow rays take one TLAS leaf per fill of the pair list (what > 1024 meshes use) instead of all
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)

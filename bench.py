@@ -295,6 +295,7 @@ class Farm:
         rays = float(st["extension_rays"] + st["shadow_rays_walked"])  # rays actually traced
         rays_ref = float(st["extension_rays"] + st["shadow_rays"])     # rays the reference path traces
         overlapped = bool(self.scene.get_option("pipelined"))
+        refilled = bool(self.scene.get_option("refilled"))  # (PMODE 1: persistent waves whose lanes draw the next pixel)
         kms = self.scene.kernel_ms_history(steps)
         kernel_ms = float(kms.mean()) if len(kms) else float("nan")
         if overlapped:
@@ -316,7 +317,7 @@ class Farm:
             self.dist.all_reduce(tsum, op=self.dist.ReduceOp.SUM)
             dt, rays, kernel_ms, rays_ref = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tsum[3])
         return dict(dt=dt, rays=rays, rays_ref=rays_ref, kernel_ms=kernel_ms, steps=steps, tuning_frames=self.tuning_frames,
-                    overlapped=overlapped,
+                    overlapped=overlapped, refilled=refilled,
                     pmode=self.scene.get_option("pmode"), merged_eff=self.scene.get_option("merged_eff"),
                     render_mode=self.scene.get_option("render_mode"))
 
@@ -335,6 +336,9 @@ def kernel_name(m):
         return "path_trace_async_kernel (asynchronous lanes)"
     shape = {0: "lock-step", 1: "pairs over LDS-staged triangles", 2: "pair queue, separate shadow phase",
              3: "TLAS rounds", 4: "pair queue, shadow rays merged into the next traversal"}[m["pmode"]]
+    if m.get("refilled"):
+        return (f"path_trace_kernel PMODE {m['pmode']} ({shape}; megakernel of persistent waves with lane refill) + "
+                "tonemap_tiles_kernel -- roofline.kernel_ms is the one-tile-per-wave kernel of a frame alone on the chip")
     return f"path_trace_kernel PMODE {m['pmode']} ({shape}; megakernel, fused tonemap)"
 
 

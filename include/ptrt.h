@@ -508,6 +508,8 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         overlap their predecessor ("pipeline"), simple materials, no post chain, spp x bounces >= 16, at least two
  *                         tiles per persistent wave (1080p 4 spp 4 bounces 1.67 -> 1.63 ms, 8 bounces 2.12 -> 1.89, 4K 6.65 -> 6.27);
  *                         2: wherever PMODE 1 runs; 0: never.  ptrt_get_option "refilled" says what the last frame did.
+ *                         ticket_tiles 1..16: consecutive tiles per draw from the queue (1; more only pays where the counter
+ *                         itself binds -- 1 spp: 0.61 -> 0.49 ms with 4, still behind the one-tile-per-wave kernel's 0.43).
  *   tlas_rounds 0|1       real TLAS: shadow rays take one TLAS leaf per fill of the pair list (what > 1024 meshes use) instead of all
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)

@@ -114,6 +114,7 @@ struct KParams {
     unsigned char *rgb8;
     int rgb8_frame; // 0: rgb8 is this context's own image (its rows, bottom-up); 1: rgb8 is the whole W x H frame (bottom-up) and
                     // the context writes its rows where they belong in it (ptrt_render, PTRT_OUT_DEVICE_FRAME)
+    int ticket_tiles;    // lane-refill variant: consecutive tiles per ticket (>= 1)
     unsigned int *queue; // lane-refill variant: {next ticket of the launch's tile queue, waves that have left}; zero between launches
     unsigned long long *counters; // COUNTER_WORDS per slot: {extension, shadow, paths, zero-valued light samples} or nullptr
 };

@@ -1657,6 +1657,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     int q_org = 0, q_next = 64;    // the tile being handed out (x0 | local y0 << 16) and the next of its 64 pixels
     uint32_t q_ticket = blockIdx.x; // lane 0: the tile drawn ahead
     bool q_first = true;
+    int q_sub = 0;        // tiles left on the current ticket
+    uint32_t q_tile = 0u; // the open tile's number
     bool q_open = STREAM;
     uint32_t n_px = 0;             // pixels this wave took (counters)
     for (;;) {
@@ -1679,14 +1681,23 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     if (!want)
                         break;
                     if (q_next == 64) { // open the next tile
-                        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_ticket) + (q_first ? 0u : gridDim.x);
-                        q_first = false;
+                        // (a ticket is good for KR.ticket_tiles consecutive tiles)
+                        uint32_t t;
+                        if (q_sub > 0) {
+                            t = q_tile + 1u;
+                            --q_sub;
+                        } else {
+                            t = ((uint32_t)__builtin_amdgcn_readfirstlane((int)q_ticket) + (q_first ? 0u : gridDim.x)) * (uint32_t)KR.ticket_tiles;
+                            q_first = false;
+                            q_sub = KR.ticket_tiles - 1;
+                            if (t < (uint32_t)KR.n_tiles && lane == 0) // (-amdgpu-atomic-optimizer-strategy=None: the result is not needed before the next ticket's first tile)
+                                q_ticket = atomicAdd(KR.queue, 1u);
+                        }
                         if (t >= (uint32_t)KR.n_tiles) {
                             q_open = false;
                             break;
                         }
-                        if (lane == 0) // (-amdgpu-atomic-optimizer-strategy=None: the result is not needed before the next tile)
-                            q_ticket = atomicAdd(KR.queue, 1u);
+                        q_tile = t;
                         const int trow = (int)t / KR.tiles_x, tcol = (int)t - trow * KR.tiles_x;
                         q_org = (tcol * 8) | ((KR.split_n > 1 ? trow * KR.split_n + KR.split_i : trow) * 8) << 16;
                         q_next = 0;

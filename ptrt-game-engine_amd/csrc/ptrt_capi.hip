@@ -170,6 +170,7 @@ struct ptrt_ctx {
     int refill = 1;
     bool refill_eff = false;         // ... the last frame
     unsigned int *d_queue = nullptr; // {ticket, waves out} per launch lane: [0] the stream, [1 + i] auxiliary stream i
+    int ticket_tiles = 1;            // option "ticket_tiles": consecutive tiles per ticket of the queue
     int persist = 0, n_cus = 0;      // option "persist": persistent waves per CU (0 = the variant's occupancy)
     int as_blocks[2] = {0, 0}; // resident workgroups of the <false>/<true> kernel at as_lds bytes of LDS
     size_t as_lds = 0;
@@ -634,9 +635,10 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
                 // Lane refill: persistent waves -- as many as the chip holds at this variant's occupancy (option "persist":
                 // waves per CU) -- that draw the launch's tiles from a queue; the image is tonemapped by a pass behind them.
                 K.n_tiles = g;
+                K.ticket_tiles = c->ticket_tiles;
                 K.queue = c->d_queue + 2 * (n > 1 ? 1 + i : 0); // (launches that share a queue are ordered: one stream each)
                 const int per_cu = c->persist > 0 ? c->persist : 4 * pt::waves_per_simd(PMODE, full, 1);
-                const int waves = std::min(g, c->n_cus * per_cu);
+                const int waves = std::min((g + c->ticket_tiles - 1) / c->ticket_tiles, c->n_cus * per_cu);
                 if (full)
                     hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE, 1, true>), dim3(waves), dim3(64), lds, st, K);
                 else
@@ -2834,6 +2836,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->pipeline = value ? 1 : 0;
     else if (n == "persist")
         c->persist = value < 0 ? 0 : value;
+    else if (n == "ticket_tiles")
+        c->ticket_tiles = value < 1 ? 1 : (value > 16 ? 16 : (int)value);
     else if (n == "refill")
         c->refill = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "split") { // tile rows of the frame dealt to that many concurrent launches of the megakernel (1 = one launch)
@@ -2886,7 +2890,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"persist", c->persist}, {"refill", c->refill}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"persist", c->persist}, {"refill", c->refill}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

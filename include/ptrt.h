@@ -267,7 +267,12 @@ int ptrt_set_env_map(ptrt_ctx *ctx, const float *rgba, int width, int height);
  * caller: rebuild it over the moved meshes' boxes, as the reference's commit does, and hand it to
  * ptrt_update_instances (the Scene mirror's refitObjectChanges / rebuildObjectChanges do).  A refitted tree has the boxes a
  * host refit of the same topology gives (min/max are exact), so results stay bit-comparable
- * with the oracle run on those arrays; it is NOT the tree a fresh median-split build would give. */
+ * with the oracle run on those arrays; it is NOT the tree a fresh median-split build would give.
+ * Host positions (verts_on_device == 0): the caller's buffer is its own again when the call returns, and the call does NOT
+ * wait for the stream's earlier work (the previous frame), so the host prepares frame N + 1 while the GPU renders frame N.
+ * Ordinary memory is copied into pinned staging memory of the context and crosses PCIe asynchronously on the stream; memory
+ * HIP knows as pinned crosses on a copy stream of the context into device staging (the call waits for that transfer alone)
+ * and moves into the arena on the stream. */
 int ptrt_update_vertices(ptrt_ctx *ctx, int mesh_index, const float *verts, int vert_count, int verts_on_device);
 int ptrt_refit(ptrt_ctx *ctx);
 

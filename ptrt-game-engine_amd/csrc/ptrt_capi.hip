@@ -169,6 +169,15 @@ struct ptrt_ctx {
     // pay -- frames that overlap their predecessor, simple materials, no post chain, spp * bounces >= 16 --, 2 wherever PMODE 1 runs (tests)
     int refill = 1;
     bool refill_eff = false;         // ... the last frame
+    static constexpr int STAGES = 4;
+    void *h_stage[STAGES] = {nullptr, nullptr, nullptr, nullptr}; // ptrt_update_vertices from host memory: pinned staging, in rotation
+    size_t stage_bytes[STAGES] = {0, 0, 0, 0};
+    hipEvent_t stage_ev[STAGES] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long stage_n = 0;
+    float *d_stage[STAGES] = {nullptr, nullptr, nullptr, nullptr}; // ... from PINNED host memory: device staging behind a copy stream
+    size_t d_stage_bytes[STAGES] = {0, 0, 0, 0};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev = nullptr;
     unsigned int *d_queue = nullptr; // {ticket, waves out} per launch lane: [0] the stream, [1 + i] auxiliary stream i
     int ticket_tiles = 1;            // option "ticket_tiles": consecutive tiles per ticket of the queue
     int persist = 0, n_cus = 0;      // option "persist": persistent waves per CU (0 = the variant's occupancy)
@@ -1226,6 +1235,17 @@ void ptrt_destroy(ptrt_ctx *c) {
     dfree(c->d_rgb8);
     dfree(c->d_counters);
     dfree(c->d_queue);
+    for (int k = 0; k < ptrt_ctx::STAGES; ++k) {
+        if (c->h_stage[k])
+            (void)hipHostFree(c->h_stage[k]);
+        if (c->stage_ev[k])
+            (void)hipEventDestroy(c->stage_ev[k]);
+        dfree(c->d_stage[k]);
+    }
+    if (c->copy_stream)
+        (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_ev)
+        (void)hipEventDestroy(c->copy_ev);
     dfree(c->wf_st);
     dfree(c->wf_occ);
     dfree(c->wf_live);
@@ -1756,10 +1776,62 @@ int ptrt_update_vertices(ptrt_ctx *c, int mesh, const float *verts, int vert_cou
                     mesh, (mesh >= 0 && mesh < c->n_meshes) ? c->mesh_vert_count[mesh] : -1, vert_count);
     if (int rc = set_device(c))
         return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->d_verts + (size_t)c->mesh_vert_base[mesh] * 3, verts, (size_t)vert_count * 12,
-                              on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    if (!on_device)
-        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller may reuse its host buffer
+    const size_t bytes = (size_t)vert_count * 12;
+    float *dst = c->d_verts + (size_t)c->mesh_vert_base[mesh] * 3;
+    if (on_device) {
+        HIP_TRY(c, hipMemcpyAsync(dst, verts, bytes, hipMemcpyDeviceToDevice, c->stream));
+        return PTRT_OK;
+    }
+    // Host positions: the caller may reuse its buffer the moment this returns.  Waiting for the copy would mean waiting for
+    // everything in front of it on the stream -- the previous frame's trace -- so the host could not prepare frame N + 1 while the
+    // GPU renders frame N (the reference's updatePTScene -> commitObjectChanges() loop: 2.04 ms per fluid frame, host and GPU
+    // in turn).  The positions go through one of four pinned staging buffers of the context instead and cross PCIe behind the
+    // stream's work; a buffer is waited for only when it comes round again, four updates later.
+    constexpr size_t STAGE_MAX = (size_t)256 << 20;
+    if (bytes > STAGE_MAX) {
+        HIP_TRY(c, hipMemcpyAsync(dst, verts, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return PTRT_OK;
+    }
+    const int k = (int)(c->stage_n++ % ptrt_ctx::STAGES);
+    if (c->stage_ev[k])
+        HIP_TRY(c, hipEventSynchronize(c->stage_ev[k]));
+    else
+        HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming));
+    // (Positions already in PINNED memory need no host copy: they cross PCIe on a stream of their own into a device staging
+    // buffer -- the call waits for that transfer alone, ~0.1 ms for 4.7 MB -- and move into the arena on the context's stream.)
+    hipPointerAttribute_t pa;
+    if (hipPointerGetAttributes(&pa, verts) == hipSuccess && pa.type == hipMemoryTypeHost) {
+        if (!c->copy_stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+        }
+        if (c->d_stage_bytes[k] < bytes) {
+            dfree(c->d_stage[k]);
+            c->d_stage_bytes[k] = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_stage[k], bytes));
+            c->d_stage_bytes[k] = bytes;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage[k], verts, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(c->copy_ev, c->copy_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream)); // the caller's buffer is its own again
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
+        HIP_TRY(c, hipMemcpyAsync(dst, c->d_stage[k], bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->stage_ev[k], c->stream)); // (the staging buffer is free again behind this)
+        return PTRT_OK;
+    }
+    (void)hipGetLastError(); // (an address HIP does not know is ordinary host memory)
+    if (c->stage_bytes[k] < bytes) {
+        if (c->h_stage[k])
+            HIP_TRY(c, hipHostFree(c->h_stage[k]));
+        c->h_stage[k] = nullptr;
+        c->stage_bytes[k] = 0;
+        HIP_TRY(c, hipHostMalloc(&c->h_stage[k], bytes, hipHostMallocDefault));
+        c->stage_bytes[k] = bytes;
+    }
+    std::memcpy(c->h_stage[k], verts, bytes);
+    HIP_TRY(c, hipMemcpyAsync(dst, c->h_stage[k], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->stage_ev[k], c->stream));
     return PTRT_OK;
 }
 

@@ -374,8 +374,8 @@ def roofline_block(config_name, kernel_ms, pixels):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)  # (the queue modes settle their loop shape on frames 4-8: ptrt_set_option merged)
+    ap.add_argument("--steps", type=int, default=100)   # (short runs are bimodal on a fresh box: the first ~30 frames after start-up can
+    ap.add_argument("--warmup", type=int, default=40)   #  run at half speed -- fluid 1.0 vs 1.85 ms with 12 + 30 frames; 40 + 100 is 0.3 s)  # (the queue modes settle their loop shape on frames 4-8: ptrt_set_option merged)
     ap.add_argument("--config", default="cornell1080", choices=sorted(CONFIGS))
     ap.add_argument("--scene", default=None, help="override the config's scene (also: many, matrix)")
     ap.add_argument("--width", type=int, default=None)

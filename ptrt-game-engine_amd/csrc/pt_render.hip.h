@@ -1432,6 +1432,12 @@ namespace pt {
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 3
 #endif
+#ifndef PT_PRIO_B
+#define PT_PRIO_B 1 // PMODE 1: s_setprio of the closest-hit phase [B] ...
+#endif
+#ifndef PT_PRIO_D
+#define PT_PRIO_D 1 // ... and of the shadow phase [D]; the shading phases run at 0
+#endif
 
 // Waves per SIMD a variant is built for (= its register budget: 512 / waves, in steps of 8).  PMODE 1 with the simple
 // materials -- a whole small scene in 7.5 KB of LDS, no traversal stacks -- runs five (96 VGPRs; the Cornell kernel then
@@ -1831,6 +1837,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(8, t_pa);
         PT_MARK("B");
+        if (PMODE == 1 && PT_PRIO_B)
+            __builtin_amdgcn_s_setprio(PT_PRIO_B);
         const KParams &KB = kparams(kp0);
         // ---- [B] closest hit, all live lanes together (PMODE 4: and the parked shadow rays in the same traversal)
         Hit h;
@@ -1859,6 +1867,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         }
 
         PT_MARK("C");
+        if (PMODE == 1 && PT_PRIO_B)
+            __builtin_amdgcn_s_setprio(0);
         const KParams &KC = kparams(kp0);
         const unsigned long long t_pc = TS_NOW();
         // ---- [C] first half of the shading
@@ -2041,6 +2051,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(10, t_pc2);
         PT_MARK("D");
+        if (PMODE == 1 && PT_PRIO_D)
+            __builtin_amdgcn_s_setprio(PT_PRIO_D);
         const KParams &KD = kparams(kp0);
         // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas); PMODE 4 parks them instead and
         // walks them with the next extension rays
@@ -2064,6 +2076,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         TS_ADD(13, t_sh);
 
         PT_MARK("E");
+        if (PMODE == 1 && PT_PRIO_D)
+            __builtin_amdgcn_s_setprio(0);
         const KParams &KE = kparams(kp0);
         const unsigned long long t_pe = TS_NOW();
         // ---- [E] second half of the shading

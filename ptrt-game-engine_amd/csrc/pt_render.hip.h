@@ -1432,12 +1432,16 @@ namespace pt {
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 3
 #endif
-#ifndef PT_PRIO_B
-#define PT_PRIO_B 1 // PMODE 1: s_setprio of the closest-hit phase [B] ...
+// PMODE 1: the phases of the render loop that run at s_setprio 1 -- bit 0 [R]+[A], 1 [B], 2 [C], 3 [C2], 4 [D], 5 [E] -- the others
+// at 0.  The traversal phases are short chains of LDS reads, each waited for: a wave in one of them that loses the issue
+// arbitration to four waves in their VALU-dense shading phases leaves its LDS requests unissued.
+#ifndef PT_PRIO_MASK
+#define PT_PRIO_MASK 0x1b
 #endif
-#ifndef PT_PRIO_D
-#define PT_PRIO_D 1 // ... and of the shadow phase [D]; the shading phases run at 0
-#endif
+template <int PMODE, int PHASE, int PREV> PT_DEV void phase_prio() {
+    if (PMODE == 1 && ((PT_PRIO_MASK >> PHASE) & 1) != ((PT_PRIO_MASK >> PREV) & 1))
+        __builtin_amdgcn_s_setprio((PT_PRIO_MASK >> PHASE) & 1);
+}
 
 // Waves per SIMD a variant is built for (= its register budget: 512 / waves, in steps of 8).  PMODE 1 with the simple
 // materials -- a whole small scene in 7.5 KB of LDS, no traversal stacks -- runs five (96 VGPRs; the Cornell kernel then
@@ -1668,6 +1672,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     bool q_open = STREAM;
     uint32_t n_px = 0;             // pixels this wave took (counters)
     for (;;) {
+        phase_prio<PMODE, 0, 5>();
         if (STREAM) {
             // ---- [R] lanes without work: write the finished pixel out, take the next one.  Which lane renders a pixel
             // changes nothing in it: generator state, samples and sums are the pixel's own.
@@ -1837,8 +1842,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(8, t_pa);
         PT_MARK("B");
-        if (PMODE == 1 && PT_PRIO_B)
-            __builtin_amdgcn_s_setprio(PT_PRIO_B);
+        phase_prio<PMODE, 1, 0>();
         const KParams &KB = kparams(kp0);
         // ---- [B] closest hit, all live lanes together (PMODE 4: and the parked shadow rays in the same traversal)
         Hit h;
@@ -1867,8 +1871,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         }
 
         PT_MARK("C");
-        if (PMODE == 1 && PT_PRIO_B)
-            __builtin_amdgcn_s_setprio(0);
+        phase_prio<PMODE, 2, 1>();
         const KParams &KC = kparams(kp0);
         const unsigned long long t_pc = TS_NOW();
         // ---- [C] first half of the shading
@@ -2006,6 +2009,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(9, t_pc);
         PT_MARK("C2");
+        phase_prio<PMODE, 3, 2>();
         const KParams &KC2 = kparams(kp0);
         const unsigned long long t_pc2 = TS_NOW();
         // ---- [C2] the light sample's value, BEFORE its visibility is known (path_logic.cuh:840-867: bsdf * radiance *
@@ -2051,8 +2055,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(10, t_pc2);
         PT_MARK("D");
-        if (PMODE == 1 && PT_PRIO_D)
-            __builtin_amdgcn_s_setprio(PT_PRIO_D);
+        phase_prio<PMODE, 4, 3>();
         const KParams &KD = kparams(kp0);
         // ---- [D] shadow rays, all lanes that have one together (bvh_any_hit_tlas); PMODE 4 parks them instead and
         // walks them with the next extension rays
@@ -2076,8 +2079,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         TS_ADD(13, t_sh);
 
         PT_MARK("E");
-        if (PMODE == 1 && PT_PRIO_D)
-            __builtin_amdgcn_s_setprio(0);
+        phase_prio<PMODE, 5, 4>();
         const KParams &KE = kparams(kp0);
         const unsigned long long t_pe = TS_NOW();
         // ---- [E] second half of the shading

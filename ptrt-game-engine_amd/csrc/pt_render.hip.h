@@ -1911,7 +1911,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 end_path = true;
             } else {
                 shaded = true;
-                if (PMODE == 1 && mats_lds) { // the triangle and the mesh's flags are in LDS
+                if (PMODE == 1) { // the triangle and the mesh's flags are in LDS
                     const int ti = (h.slot * 3 + h_order * PAIR_PAD) * 4;
                     const f3 gn = mk3(lds_ld1((const float *)PL.tris, ti + 3), lds_ld1((const float *)PL.tris, ti + 7),
                                       lds_ld1((const float *)PL.tris, ti + 11));

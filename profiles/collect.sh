@@ -12,3 +12,8 @@ done
 cd $R
 ( for c in "cornell1080:cornell 1920 1080 4" "showcase1080:showcase 1920 1080 4" "fluid:fluid 1920 1080 2" "many:many 1920 1080 4"; do echo "### ${c%%:*}"; PTRT_AMD_LIB=$V/libptrt_stats.so python tools/trav_stats.py ${c#*:}; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/prof_lane/lane_occupancy.txt
 tail -5 gpurun_out/prof_lane/lane_occupancy.txt
+# the default run's frames overlap (and PMODE 1 runs its lane-refill kernel): what the trace saw -> profiles/overlap_trace.py
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_overlap -- python3 $R/bench.py --steps 40 --warmup 20 --no-cpu-baseline --no-configs3 > $R/gpurun_out/prof_overlap.log 2>&1 )
+( echo "### cornell1080, lane refill (refill=2: every frame, also alone on the chip)"; PTRT_AMD_LIB=$V/libptrt_stats.so python tools/trav_stats.py cornell 1920 1080 4 refill=2 ) 2>&1 | grep -v amdgpu.ids >> gpurun_out/prof_lane/lane_occupancy.txt
+tail -3 gpurun_out/prof_lane/lane_occupancy.txt
+

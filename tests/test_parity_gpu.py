@@ -45,6 +45,46 @@ def test_cornell_lane_refill(P, O, blue_noise, size, spp, depth, frames, kw):
     s.close()
 
 
+def test_lane_refill_queue_shapes(P):
+    """The tile queue of the lane-refill kernel at its edges: frames of a few pixels to a few hundred tiles with ragged right
+    and bottom edges, one persistent wave to more waves than tiles, tickets good for 1..5 tiles (a last ticket that reaches past
+    the launch), 1 spp (a lane finishes a pixel every iteration) and long paths.  Every buffer, generator state and ray count
+    equals the one-tile-per-wave kernel's (which the other tests hold to the oracle), over three frames."""
+    import random
+    rnd = random.Random(20261005)
+    cases = [(1, 1), (8, 8), (9, 1), (1, 9), (64, 8), (65, 9)] + [(rnd.randint(2, 150), rnd.randint(2, 90)) for _ in range(18)]
+    for k, (W, H) in enumerate(cases):
+        spp, depth = rnd.choice([(1, 1), (1, 4), (2, 3), (3, 5), (4, 4)])
+        opts = dict(persist=rnd.choice([0, 1, 1, 2, 3]), ticket_tiles=rnd.choice([1, 1, 2, 3, 5]))
+        frames = {}
+        for refill in (0, 2):
+            s = P.Scene(W, H)
+            (P.scenes.cornell if k % 3 else (lambda sc: P.scenes.cornell(sc, quads=True)))(s)
+            s.setPerfSamplesPerPixel(spp)
+            s.setMaxBounceDepth(depth)
+            s.setDenoiserEnabled(False)
+            s.setBloomEnabled(False)
+            s.initBlueNoise()
+            s.uploadToGPU()
+            s.set_option("count_rays", 1)
+            s.set_option("refill", refill)
+            for name, v in opts.items():
+                s.set_option(name, v)
+            out = []
+            for _ in range(3):
+                rgb = s.render_to_host()
+                assert s.get_option("refilled") == (1 if refill else 0)
+                out.append((rgb, s.read(P.BUF_ACCUM), s.read(P.BUF_RNG), s.read(P.BUF_NORMAL), s.read(P.BUF_DEPTH),
+                            s.read(P.BUF_OBJECT_ID), s.stats()))
+            frames[refill] = out
+            s.close()
+        for f, (a, b) in enumerate(zip(frames[0], frames[2])):
+            for i in range(6):
+                av, bv = (a[i].view(np.uint32), b[i].view(np.uint32)) if a[i].dtype == np.float32 else (a[i], b[i])
+                assert np.array_equal(av, bv), f"case {k} {W}x{H} spp {spp} depth {depth} {opts} frame {f}: buffer {i} differs"
+            assert a[6] == b[6], f"case {k} {W}x{H} {opts} frame {f}: {a[6]} vs {b[6]}"
+
+
 def test_lane_refill_over_interleaved_strips_and_into_a_shared_frame(P):
     """Lane refill on contexts that own every third 8-row strip, each writing its rows straight into ONE device frame
     (PTRT_OUT_DEVICE_FRAME): the frame and the strips' HDR rows are the full-frame context's (classic kernel)."""

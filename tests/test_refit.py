@@ -92,6 +92,44 @@ def test_refit_from_device_memory(P, O, blue_noise):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_refit_from_host_memory_does_not_wait_and_does_not_keep_the_buffer(P, O, blue_noise, pinned):
+    """ptrt_update_vertices from host memory returns without waiting for the stream (ordinary memory: staged in pinned memory
+    of the context; pinned memory: a copy stream + device staging) and the caller's buffer is its own again at once: it is
+    overwritten with other positions right after every call -- five updates in a row, more than the staging ring holds, with
+    frames in flight -- and the frames still are the ones of the positions handed over."""
+    import torch
+    W, H = 96, 64
+    times = [0.2, 0.9, 1.7, 2.4, 3.1]
+    want = []
+    ref = P.Scene(W, H)
+    w, _ = P.scenes.fluid(ref, cells=24, t=0.0, ship_segments=8)
+    render_both(P, O, ref, blue_noise, 1, 3, 1)
+    for t in times:
+        ref.setVertices(w, P.scenes.water_vertices(24, t))
+        ref.refitObjectChanges()
+        want.append(ref.render_to_host().copy())
+    ref.close()
+    s = P.Scene(W, H)
+    w, _ = P.scenes.fluid(s, cells=24, t=0.0, ship_segments=8)
+    render_both(P, O, s, blue_noise, 1, 3, 1)
+    n = P.scenes.water_vertices(24, 0.0).size
+    buf = torch.empty(n, dtype=torch.float32)
+    if pinned:
+        buf = buf.pin_memory()
+    dev = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in times]
+    for k, t in enumerate(times):
+        buf.numpy()[:] = np.ascontiguousarray(P.scenes.water_vertices(24, t)).ravel()
+        s.refitFromHost(w, buf.data_ptr())
+        buf.numpy()[:] = 1e9  # the caller's buffer is the caller's again
+        s.render_to_device(dev[k].data_ptr())
+    s.sync()
+    for k in range(len(times)):
+        assert np.array_equal(dev[k].cpu().numpy(), want[k]), f"frame {k}"
+    s.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rebuild", [False, True])
 def test_refit_and_rebuild_behind_a_real_tlas(P, O, blue_noise, rebuild):
     """A vertex-animated mesh among > 17 meshes: BLAS refit (or GPU rebuild) on the GPU, TLAS rebuilt by the host

@@ -273,3 +273,36 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
         assert np.array_equal(a_rgb, b_rgb) and np.array_equal(a_acc.view(np.uint32), b_acc.view(np.uint32))
         assert np.array_equal(a_rng, b_rng) and a_st == b_st
     assert on[1][0].any()
+
+
+def test_lane_refill_is_chosen_where_it_pays(P):
+    """ptrt_render's rule for the lane-refill kernel (option "refill" = 1, the default): PMODE 1 frames that overlap
+    their predecessor, with the simple materials, no post chain, at least 16 sample-bounces per pixel and at least two tiles
+    per persistent wave -- the BASELINE headline at its full size qualifies from its second frame on, none of the others do."""
+    import torch
+
+    def refilled(W, H, spp, depth, frames=3, post=False, scene="cornell", same_target=False):
+        s = P.Scene(W, H)
+        (P.scenes.cornell if scene == "cornell" else (lambda sc: P.scenes.showcase(sc, segments=8)))(s)
+        s.setPerfSamplesPerPixel(spp)
+        s.setMaxBounceDepth(depth)
+        s.setDenoiserEnabled(post)
+        s.setBloomEnabled(False)
+        s.initBlueNoise()
+        s.uploadToGPU()
+        s.set_option("merged", 0)
+        tgt = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        out = []
+        for f in range(frames):
+            s.render_to_device(tgt[0 if same_target else f & 1].data_ptr())
+            out.append(s.get_option("refilled"))
+        s.close()
+        return out
+
+    assert refilled(1920, 1080, 4, 4) == [0, 1, 1]                      # the headline: every frame that overlaps
+    assert refilled(1920, 1080, 4, 4, same_target=True) == [0, 0, 0]    # one target: frames wait for the stream
+    assert refilled(1920, 1080, 1, 4) == [0, 0, 0]                      # short pixels
+    assert refilled(1920, 1080, 4, 4, post=True) == [0, 0, 0]           # a post chain beside the trace
+    assert refilled(640, 360, 4, 4) == [0, 0, 0]                        # too few tiles per persistent wave
+    assert refilled(1920, 1080, 4, 4, scene="showcase") == [0, 0, 0]    # trees: not PMODE 1
+

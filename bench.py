@@ -236,6 +236,12 @@ class Farm:
         b = self.counter[1] & 1
         self.counter[1] += 1
         self._retire(b)
+        if self.pending[b ^ 1] is not None and s.get_option("pipelined"):
+            # Frames overlap (ptrt_set_option "pipeline"): the NEXT frame, into the other buffer, will wait only for what is on
+            # the scene's stream when THIS render call is made -- so that buffer's consumer, the collective of the previous
+            # frame (it runs on the communicator's stream), has to be on the scene's stream by now (include/ptrt.h).  The
+            # wait is the stream's, not the host's, and this frame's launches do not wait for the stream.
+            self._retire(b ^ 1)
         s.render_to_device(self.tiles[b].data_ptr())
         if self.post_on_rank0:
             src = {k: (t.cpu() if rehearse else t) for k, t in self.gband.items()}

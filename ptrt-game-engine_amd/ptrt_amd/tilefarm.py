@@ -10,6 +10,11 @@ the assembled frame a plain concatenation of the band images in reverse rank ord
 The exchange is one gather per frame (0.78 MB per rank at 1080p / 8 GPUs: latency-, not
 bandwidth-bound on xGMI).  `gather_bands(..., async_op=True)` returns a handle so the caller can
 render frame i+1 while frame i's bands are still in flight (double-buffered band images).
+With overlapping frames (ptrt_set_option "pipeline", the default) a frame into image A waits only for
+what was on the scene's stream when the PREVIOUS render call was made: the collective that still
+reads A runs on the communicator's stream, so `.wait()` on its handle -- a wait of the current
+stream, not of the host -- belongs before the render call in between (bench.py, Farm.step), not just
+before the one that overwrites A.
 """
 
 

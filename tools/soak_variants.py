@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak check (GPU box, repo root): 24 consecutive 1080p frames with a wandering camera on four scenes, rendered
 by the default traversal, by the plain one (batches of 64 pairs, every lane its own leaf, no stealing, no yield,
-one lane per pair) and by the lock-step mesh loop; every frame's HDR image, object ids, generator states and ray
+one lane per pair), by the lock-step mesh loop and (PMODE 1) by the lane-refill kernel; every frame's HDR image, object ids, generator states and ray
 counts must be identical.  (tests/test_misc_gpu.py holds the two-frame version with the async and wavefront
 kernels; this one is for more rays.)"""
 import sys, os
@@ -24,9 +24,10 @@ plain = dict(fetch_min=0, leaf_pairs=0, steal=0, leaf_min=64, pair_split=0)
 for name, build, spp in (("showcase", P.scenes.showcase, 4), ("fluid", lambda s: P.scenes.fluid(s, cells=256, t=0.7), 2),
                          ("many", lambda s: _many_meshes(P, s, n=60), 4), ("cornell", P.scenes.cornell, 4)):
     a = frames(build, {}, 24, spp); b = frames(build, plain, 24, spp); c = frames(build, dict(pair_trace=0), 24, spp)
+    d = frames(build, dict(refill=2, persist=7), 24, spp)  # (PMODE 1: persistent waves with lane refill, 1,792 of them for 32,400 tiles)
     bad = 0
-    for f, (x, y, z) in enumerate(zip(a, b, c)):
+    for f, (x, y, z, w) in enumerate(zip(a, b, c, d)):
         for k in range(3):
-            if not (np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k])): bad += 1
-        if not (x[3] == y[3] == z[3]): bad += 1
-    print(name, "24 frames x 3 variants:", "IDENTICAL" if bad == 0 else f"{bad} MISMATCHES", a[-1][3])
+            if not (np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k]) and np.array_equal(x[k], w[k])): bad += 1
+        if not (x[3] == y[3] == z[3] == w[3]): bad += 1
+    print(name, "24 frames x 4 variants:", "IDENTICAL" if bad == 0 else f"{bad} MISMATCHES", a[-1][3])

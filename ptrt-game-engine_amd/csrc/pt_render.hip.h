@@ -175,7 +175,7 @@ PT_DEV PairLds carve_pair_lds_wg(void *base, int wave, int meshes, int stack_ent
 // wave is in each loop of the PMODE 2 traversals.  [0..7] closest, [8..15] any-hit:
 // calls, pairs, node wave-iterations, node lane-steps, leaf phases, triangle wave-iterations,
 // triangle lane-tests, outer iterations; [16] persistent-loop iterations, [17] live lanes in them.
-__device__ unsigned long long g_trav_stats[32]; // [0..7] closest, [8..15] any-hit, [16..17] loop, [24..31] cycles (CycleAcc)
+__device__ unsigned long long g_trav_stats[32]; // [0..7] closest, [8..15] any-hit, [16..17] loop, [18..23] lanes per phase (TS_LANES), [24..31] cycles (CycleAcc)
 // -DPT_MARKS: "; MARK x" comments in the ISA at the phase boundaries of path_trace_kernel (tools/asm_phases.py counts the
 // instructions between them)
 #ifdef PT_MARKS
@@ -213,6 +213,13 @@ struct CycleAcc {
                 atomicAdd(&g_trav_stats[24 + i], c[i]);
     }
 };
+// lanes for which `cond` holds, summed over the wave-level executions of the statement ([18..23]: per-phase participation)
+#define TS_LANES(slot, cond)                                                                                             \
+    do {                                                                                                                 \
+        const unsigned long long ts_m = __builtin_amdgcn_ballot_w64(cond);                                               \
+        if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))                                                   \
+            atomicAdd(&g_trav_stats[slot], (unsigned long long)__builtin_popcountll(ts_m));                                 \
+    } while (0)
 #define TS_NOW() __builtin_readcyclecounter()
 #define TS_ADD(slot, t) (cyc.c[(slot) - 8] += __builtin_readcyclecounter() - (t))
 #define TS_ADDL(slot, t) (L.cyc->c[(slot) - 8] += __builtin_readcyclecounter() - (t))
@@ -225,6 +232,7 @@ struct TravStats {
 struct CycleAcc {
     PT_DEV void flush(int) {}
 };
+#define TS_LANES(slot, cond)
 #define TS_NOW() 0ull
 #define TS_ADD(slot, t) (void)(t)
 #define TS_ADDL(slot, t) (void)(t)
@@ -1727,6 +1735,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 // (the finished pixel's state moves to spare registers and is stored LAST: nothing waits for stores then)
                 const Rng rng_old = rng;
                 const f3 avg_old = avg_color;
+                TS_LANES(22, got >= 0);
+                TS_LANES(23, true);
                 if (got >= 0) {
                     float2 bnv = make_float2(0.0f, 0.0f);
                     if (STAGED) { // (no memory operation inside the loop above, none conditional here: the compiler's
@@ -1795,6 +1805,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         const KParams &KA = kparams(kp0);
         const unsigned long long t_pa = TS_NOW();
         // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
+        TS_LANES(18, live && fresh);
         if (live && fresh) {
             const int x = px(), y = global_row(pyl(), KA.y0, KA.il_period, KA.il_phase);
             float tjx, tjy, bnx, bny;
@@ -1996,6 +2007,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 }
             }
         }
+        TS_LANES(19, shaded);
+        TS_LANES(20, want_shadow);
         if (LDS_COUNT) {
             const unsigned long long add = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)) |
                                            ((unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow)) << 32);
@@ -2054,6 +2067,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         }
         if (PMODE == 1)
             TS_ADD(10, t_pc2);
+        TS_LANES(21, lit);
         PT_MARK("D");
         phase_prio<PMODE, 4, 3>();
         const KParams &KD = kparams(kp0);

@@ -69,3 +69,8 @@ if cy[14]:  # instrumented build: where a wave's cycles go (s_memtime, summed ov
     if v[2] and v[5]:
         print(f"   per closest node wave-iteration {cy[9] / v[2]:.0f} units, per closest triangle wave-iteration {cy[10] / v[5]:.0f} units")
 print(f"persistent loop: {v[16]} iterations, live lanes {100.0 * v[17] / max(1, v[16] * 64):.1f} %")
+if v[16] and any(v[18:24]):  # who takes part in the phases of an iteration (lanes of 64, averaged over ALL iterations)
+    it = v[16] * 64.0
+    print(f"   of 64 lanes per iteration: [A] starts a sample {100 * v[18] / it:.1f} %, [C]/[E] shades a hit {100 * v[19] / it:.1f} %, [C] samples a "
+          f"light {100 * v[20] / it:.1f} %, [D] walks its shadow ray {100 * v[21] / it:.1f} %" +
+          (f", [R] takes a pixel {100 * v[22] / it:.1f} % (the block runs in {100.0 * v[23] / 64 / v[16]:.1f} % of the iterations)" if v[23] else ""))

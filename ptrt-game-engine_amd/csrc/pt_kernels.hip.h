@@ -106,6 +106,7 @@ struct KParams {
     int split_n, split_i; // the frame's tile ROWS are dealt to split_n concurrent launches (0 / 1: one launch); this one takes rows
                           // split_i, split_i + split_n, ...
     int spp, max_depth, frame_count;
+    int sample_sync; // 1: the lanes of a wave start their samples together (path_trace_kernel [A])
     // buffers (tile-sized)
     uint32_t *rng;    // 6 planes of rng_plane words (the context's rows*width; larger than the frame at a reduced render size)
     size_t rng_plane;

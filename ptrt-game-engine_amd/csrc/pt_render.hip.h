@@ -1805,8 +1805,13 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         const KParams &KA = kparams(kp0);
         const unsigned long long t_pa = TS_NOW();
         // ---- [A] primary ray (scene_kernels.cuh:147-167, camera.cuh:156-205)
-        TS_LANES(18, live && fresh);
-        if (live && fresh) {
+        // K.sample_sync: a lane whose path has ended starts its next sample only when NO lane of the wave is in the middle of one.
+        // The lanes then sit at the same bounce: a first hit samples no light (ray_spec), so the light-sample phases [C2] and
+        // [D] are skipped by the whole wave in that iteration instead of running for the half of the lanes that are deeper,
+        // and [A] runs once per sample for 64 lanes instead of every iteration for a quarter of them.
+        const bool hold = KA.sample_sync && __builtin_amdgcn_ballot_w64(live && !fresh) != 0ull;
+        TS_LANES(18, live && fresh && !hold);
+        if (live && fresh && !hold) {
             const int x = px(), y = global_row(pyl(), KA.y0, KA.il_period, KA.il_phase);
             float tjx, tjy, bnx, bny;
             if (STAGED && jit_lds) {
@@ -1852,6 +1857,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
 
         if (PMODE == 1)
             TS_ADD(8, t_pa);
+        const bool act = live && !fresh; // (has a ray: every live lane, unless K.sample_sync keeps it waiting)
         PT_MARK("B");
         phase_prio<PMODE, 1, 0>();
         const KParams &KB = kparams(kp0);
@@ -1861,7 +1867,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (MERGED) {
             bool blocked = false;
             const unsigned long long t_tr = TS_NOW();
-            trace_merged(KB, PL, lane, live, ro, rd, pending, park_o, park_d, park_tmax, h, blocked, cyc);
+            trace_merged(KB, PL, lane, act, ro, rd, pending, park_o, park_d, park_tmax, h, blocked, cyc);
             TS_ADD(12, t_tr);
             if (pending && !blocked)
                 acc = acc + pend; // the light sample of the previous vertex (path_logic.cuh:840-867), in its place
@@ -1874,10 +1880,10 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             }
         } else {
             const unsigned long long t_tr = TS_NOW();
-            h = (PMODE == 1)   ? closest_hit_pairs(KB, PL, lane, live, ro, rd, h_order)
-                : (PMODE == 2) ? closest_hit_pairs_dyn(KB, PL, lane, live, ro, rd)
-                : (PMODE == 3) ? closest_hit_pairs_tlas(KB, PL, lane, live, ro, rd, cyc)
-                               : closest_hit<GEOM>(KB, live, ro, rd, stk);
+            h = (PMODE == 1)   ? closest_hit_pairs(KB, PL, lane, act, ro, rd, h_order)
+                : (PMODE == 2) ? closest_hit_pairs_dyn(KB, PL, lane, act, ro, rd)
+                : (PMODE == 3) ? closest_hit_pairs_tlas(KB, PL, lane, act, ro, rd, cyc)
+                               : closest_hit<GEOM>(KB, act, ro, rd, stk);
             TS_ADD(12, t_tr);
         }
 
@@ -1894,8 +1900,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         f3 L = mk3(0.0f), light_scale = mk3(0.0f), shadow_o = mk3(0.0f);
         float pdf_sample = 1.0f, shadow_tmax = 0.0f, light_att = 1.0f;
         if (!LDS_COUNT)
-            n_ext += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
-        if (live) {
+            n_ext += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+        if (act) {
             if (h.mesh < 0) {
                 if (bounce == 0 && s == 0) { // G-buffer of the first sample's first hit (scene_kernels.cuh:181-193)
                     const size_t idx = pidx(KC.width);
@@ -2010,7 +2016,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         TS_LANES(19, shaded);
         TS_LANES(20, want_shadow);
         if (LDS_COUNT) {
-            const unsigned long long add = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)) |
+            const unsigned long long add = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act)) |
                                            ((unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow)) << 32);
             if (lane == 0)
                 __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long *)lds_count, add, __ATOMIC_RELAXED,
@@ -2128,7 +2134,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 }
             }
         }
-        if (live && end_path) {
+        if (act && end_path) {
             if (MERGED && pending) {
                 fin = true; // closed after the next traversal, once the parked light sample is in
             } else {

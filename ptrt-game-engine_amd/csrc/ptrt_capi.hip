@@ -179,6 +179,8 @@ struct ptrt_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev = nullptr;
     unsigned int *d_queue = nullptr; // {ticket, waves out} per launch lane: [0] the stream, [1 + i] auxiliary stream i
+    int sample_sync = -1;            // option "sample_sync": -1 (default) where it was measured to pay, 0 never, 1 always (ptrt_render)
+    int sample_sync_eff = 0;         // ... the last frame
     int ticket_tiles = 1;            // option "ticket_tiles": consecutive tiles per ticket of the queue
     int persist = 0, n_cus = 0;      // option "persist": persistent waves per CU (0 = the variant's occupancy)
     int as_blocks[2] = {0, 0}; // resident workgroups of the <false>/<true> kernel at as_lds bytes of LDS
@@ -2321,6 +2323,15 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         HIP_TRY(c, hipEventRecord(he, c->stream));
         ++c->head_n;
     }
+    // Samples in step (path_trace_kernel [A], K.sample_sync): the lanes of a wave start a sample together, so a wave's lanes sit at the
+    // same bounce -- a first hit samples no light and the whole wave skips [C2] / [D] in that iteration, [A] runs once per sample
+    // for 64 lanes instead of every iteration for a quarter of them -- at the price of lanes that wait for the longest path of
+    // the sample.  Pays while most paths run to the depth limit: Cornell 4 bounces 1.764 -> 1.638 ms (3 bounces 1.42 -> 1.26),
+    // `many` 15.9 -> 14.8; loses once Russian roulette thins the wave (5 bounces 1.966 -> 1.980, 6: 2.10 -> 2.31, 8: 2.26 ->
+    // 2.80) and on scenes of short paths (showcase 3.84 -> 3.92; the fluid frame gains 3 %).  Releasing the waiting lanes early
+    // (when few are still under way, or when many wait) was measured at every threshold and is worse than both extremes.
+    K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : ((max_depth <= 4 && (pmode == 1 || pmode == 3)) ? 1 : 0);
+    c->sample_sync_eff = K.sample_sync;
     // Lane refill (launch_trace): where it was measured to pay.  Overlapping 1080p Cornell frames 1.67 -> 1.62 ms, 8 bounces 2.12
     // -> 1.88, 4K 6.65 -> 6.27; a frame alone on the chip ends in a long drain of half-empty persistent waves (1.81 -> 1.97),
     // short pixels finish before the refill pays for itself (1 spp: 0.43 -> 0.61), and beside a post chain the persistent waves
@@ -2908,6 +2919,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->pipeline = value ? 1 : 0;
     else if (n == "persist")
         c->persist = value < 0 ? 0 : value;
+    else if (n == "sample_sync")
+        c->sample_sync = value < 0 ? -1 : (value != 0);
     else if (n == "ticket_tiles")
         c->ticket_tiles = value < 1 ? 1 : (value > 16 ? 16 : (int)value);
     else if (n == "refill")
@@ -2962,7 +2975,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"persist", c->persist}, {"refill", c->refill}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"persist", c->persist}, {"refill", c->refill}, {"sample_sync", c->sample_sync}, {"sample_sync_eff", c->sample_sync_eff}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

@@ -188,9 +188,11 @@ def test_full_size_traversal_variants_agree(P, scene):
     # merged=0: separate closest-hit and any-hit phases (PMODE 2) instead of one traversal per iteration (PMODE 4)
     # lds_nodes=1: four tiles per workgroup sharing an LDS copy of the mesh heads and of the BLAS top levels
     # pm1_wg=2: two tiles per workgroup sharing one LDS copy of a small scene, six waves per SIMD (PMODE 1)
+    # sample_sync=0 / 1: a lane starts its next sample as soon as its path has ended / the lanes of a wave start their samples
+    #   together (the default follows the depth limit and the mode; both are forced here for all four scenes)
     # refill=2: PMODE 1 as persistent waves whose lanes draw the next pixel of the launch (the default for overlapping frames)
     # tlas_rounds=1: shadow rays behind a real TLAS take one leaf per fill (the path of scenes with more than 1024 meshes)
-    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1), dict(refill=2)):
+    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1), dict(refill=2), dict(sample_sync=0), dict(sample_sync=1), dict(sample_sync=1, refill=2)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):
             for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):

@@ -45,6 +45,24 @@ def test_cornell_lane_refill(P, O, blue_noise, size, spp, depth, frames, kw):
     s.close()
 
 
+@pytest.mark.parametrize("sync", [0, 1])
+@pytest.mark.parametrize("scene,size,spp,depth", [("cornell", (96, 72), 4, 4), ("cornell", (61, 45), 3, 7), ("showcase", (80, 64), 2, 4),
+                                                  ("many", (72, 48), 2, 5)])
+def test_samples_in_step_or_not(P, O, blue_noise, sync, scene, size, spp, depth):
+    """ptrt_set_option "sample_sync" forced both ways (the default follows the depth limit and the traversal mode): the lanes
+    of a wave start their samples together, or each as soon as its path has ended -- the oracle's frames either way."""
+    s = P.Scene(size[0], size[1])
+    if scene == "many":
+        _many_meshes(P, s, n=40)
+    else:
+        (P.scenes.cornell if scene == "cornell" else (lambda sc: P.scenes.showcase(sc, segments=8)))(s)
+    s.set_option("sample_sync", sync)
+    gpu, cpu = render_both(P, O, s, blue_noise, spp, depth, 2)
+    assert s.get_option("sample_sync_eff") == sync
+    assert_frames_equal(gpu, cpu)
+    s.close()
+
+
 def test_lane_refill_queue_shapes(P):
     """The tile queue of the lane-refill kernel at its edges: frames of a few pixels to a few hundred tiles with ragged right
     and bottom edges, one persistent wave to more waves than tiles, tickets good for 1..5 tiles (a last ticket that reaches past

@@ -323,7 +323,7 @@ class Farm:
             self.dist.all_reduce(tsum, op=self.dist.ReduceOp.SUM)
             dt, rays, kernel_ms, rays_ref = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tsum[3])
         return dict(dt=dt, rays=rays, rays_ref=rays_ref, kernel_ms=kernel_ms, steps=steps, tuning_frames=self.tuning_frames,
-                    overlapped=overlapped, refilled=refilled,
+                    overlapped=overlapped, refilled=refilled, sample_sync=int(self.scene.get_option("sample_sync_eff")),
                     pmode=self.scene.get_option("pmode"), merged_eff=self.scene.get_option("merged_eff"),
                     render_mode=self.scene.get_option("render_mode"))
 
@@ -559,7 +559,7 @@ def main():
                    "width": W, "height": H, "spp": spp_used, "max_depth": depth_used,
                    "parallelism": (f"tile{world}-{layout}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
                    "kernel": kernel_name(m), "tuning_frames": m["tuning_frames"], "library": P.library_info(),
-                   "frames_overlap": m["overlapped"]},
+                   "frames_overlap": m["overlapped"], "samples_in_step": bool(m.get("sample_sync"))},
         "roofline": roofline_block(profile_key if world == 1 else None, kernel_ms, W * rows0),
     }
     if c3 is not None:

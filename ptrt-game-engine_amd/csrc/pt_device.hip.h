@@ -739,8 +739,10 @@ template <bool FULL> PT_DEV float material_pdf(const Surface &hit, const Materia
 // ------------------------------------------------------------ BSDF sampling
 // returns false when the path ends (no lobe left to sample)
 template <bool FULL>
+// `draws_only`: the vertex is the path's last (the depth limit follows): nothing of the scattered ray will be looked at, only
+// the generator has to move on exactly as it would -- the same uniforms drawn, the same answer, none of the arithmetic.
 PT_DEV bool material_scatter(const Surface &hit, const Material &mat, f3 ray_dir, Rng &rng, f3 &scattered_dir,
-                             f3 &attenuation, bool &is_specular_bounce) {
+                             f3 &attenuation, bool &is_specular_bounce, bool draws_only = false) {
     const f3 V = -ray_dir;
     const f3 N = hit.normal;
     const float NdotV = max_(dot(N, V), 0.0f);
@@ -776,6 +778,11 @@ PT_DEV bool material_scatter(const Surface &hit, const Material &mat, f3 ray_dir
             const float P_trans_reflect = prob_base * reflect_prob;
             const float P_trans_refract = prob_base * refract_prob;
             const float u = rng_uniform(rng);
+            if (draws_only) { // (importance_sample_ggx: two uniforms)
+                (void)rng_uniform(rng);
+                (void)rng_uniform(rng);
+                return true;
+            }
             // one GGX half-vector draw whichever lobe is chosen; only the roughness differs
             const bool pick_coat = u < P_coat;
             const bool pick_refl = !pick_coat && (u < P_coat + P_trans_reflect);
@@ -895,6 +902,8 @@ PT_DEV bool material_scatter(const Surface &hit, const Material &mat, f3 ray_dir
         const float a = r * r, a2 = a * a;
         const float u1 = rng_uniform(rng);
         const float u2r = rng_uniform(rng);
+        if (draws_only)
+            return true;
         const float u2 = ggx ? min_(u2r, 0.9999999f) : u2r;
         float sp, cp;
         det_sincos(TWO_PI_F * (ggx ? u1 : u2), sp, cp);

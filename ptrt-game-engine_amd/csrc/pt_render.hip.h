@@ -2107,7 +2107,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             const Material mat = mats_lds ? load_material<true>(PL.mats, h_order) : load_material(KE.materials, h.mesh);
             f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
             bool is_specular = false;
-            if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular)) {
+            // (the path's last vertex -- the depth limit follows: the scattered ray is never traced and the throughput never read
+            // again, so only the generator moves on, by the uniforms the reference draws here: lobe, direction, roulette.  With
+            // the samples in step this is the whole wave in one iteration of max_depth.)
+            const bool last = bounce + 1 >= KE.max_depth;
+            if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular, last)) {
                 end_path = true;
             } else {
                 prev_was_specular = is_specular;
@@ -2116,10 +2120,10 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     const float p = max_(0.05f, min_(0.95f, max_(throughput.x, max_(throughput.y, throughput.z))));
                     if (rng_uniform(rng) > p)
                         killed = true;
-                    else
+                    else if (!last)
                         throughput = throughput / p;
                 }
-                if (killed) {
+                if (killed || last) {
                     end_path = true;
                 } else {
                     throughput = throughput * att;

@@ -518,8 +518,8 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   sample_sync -1|0|1    the lanes of a wave start their samples together (1) instead of each as soon as its path has ended (0):
  *                         the wave's lanes then sit at the same bounce, the light-sample phases are skipped by the whole wave at a
  *                         first hit and the primary rays are made once per sample for 64 lanes; lanes wait for the sample's
- *                         longest path.  Same bits.  -1 (default): on where it was measured to pay -- at most 4 bounces, PMODE 1 and
- *                         3 (Cornell 1.76 -> 1.64 ms, 136 meshes 15.9 -> 14.8; 5 bounces and more lose, as do scenes of short paths).
+ *                         longest path.  Same bits.  -1 (default): on where it was measured to pay -- at most 4 bounces (Cornell
+ *                         1.76 -> 1.64 ms, 136 meshes 15.9 -> 14.8, the fluid frame -3 %, scenes of short paths even; 5 bounces and more lose).
  *                         ptrt_get_option "sample_sync_eff" says what the last frame did.
  *   tlas_rounds 0|1       real TLAS: shadow rays take one TLAS leaf per fill of the pair list (what > 1024 meshes use) instead of all
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)

@@ -2328,9 +2328,10 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // for 64 lanes instead of every iteration for a quarter of them -- at the price of lanes that wait for the longest path of
     // the sample.  Pays while most paths run to the depth limit: Cornell 4 bounces 1.764 -> 1.638 ms (3 bounces 1.42 -> 1.26),
     // `many` 15.9 -> 14.8; loses once Russian roulette thins the wave (5 bounces 1.966 -> 1.980, 6: 2.10 -> 2.31, 8: 2.26 ->
-    // 2.80) and on scenes of short paths (showcase 3.84 -> 3.92; the fluid frame gains 3 %).  Releasing the waiting lanes early
+    // 2.80); scenes of short paths are indifferent once a path's last vertex costs nothing (showcase 3.90 -> 3.90; the fluid frame
+    // gains 3 %), so the depth limit alone decides.  Releasing the waiting lanes early
     // (when few are still under way, or when many wait) was measured at every threshold and is worse than both extremes.
-    K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : ((max_depth <= 4 && (pmode == 1 || pmode == 3)) ? 1 : 0);
+    K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : (max_depth <= 4 ? 1 : 0);
     c->sample_sync_eff = K.sample_sync;
     // Lane refill (launch_trace): where it was measured to pay.  Overlapping 1080p Cornell frames 1.67 -> 1.62 ms, 8 bounces 2.12
     // -> 1.88, 4K 6.65 -> 6.27; a frame alone on the chip ends in a long drain of half-empty persistent waves (1.81 -> 1.97),

@@ -409,9 +409,13 @@ PT_DEV float2 lds_ld2(const float2 *p, int i) {
 }
 template <bool LDS> PT_DEV float4 ld4(const float4 *p, int i) { return LDS ? lds_ld4(p, i) : p[i]; }
 
-template <bool LDS = false> PT_DEV Material load_material(const float4 *__restrict__ recs, int id) {
-    const float4 a = ld4<LDS>(recs, id * 6 + 0), b = ld4<LDS>(recs, id * 6 + 1), c = ld4<LDS>(recs, id * 6 + 2),
-                 d = ld4<LDS>(recs, id * 6 + 3), e = ld4<LDS>(recs, id * 6 + 4), f = ld4<LDS>(recs, id * 6 + 5);
+// (STRIDE 3: records cut down to what the simple-material kernels read -- albedo, metallic, specular, roughness, emission,
+// transmission; the rest reads as zero and is not looked at)
+template <bool LDS = false, int STRIDE = 6> PT_DEV Material load_material(const float4 *__restrict__ recs, int id) {
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 a = ld4<LDS>(recs, id * STRIDE + 0), b = ld4<LDS>(recs, id * STRIDE + 1), c = ld4<LDS>(recs, id * STRIDE + 2),
+                 d = STRIDE > 3 ? ld4<LDS>(recs, id * STRIDE + 3) : z, e = STRIDE > 4 ? ld4<LDS>(recs, id * STRIDE + 4) : z,
+                 f = STRIDE > 5 ? ld4<LDS>(recs, id * STRIDE + 5) : z;
     Material m;
     m.albedo = mk3(a.x, a.y, a.z);
     m.metallic = a.w;

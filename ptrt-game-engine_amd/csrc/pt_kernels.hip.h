@@ -88,8 +88,7 @@ struct KParams {
     int n_tiles;        // 8x8-pixel tiles of this launch (the 4-wave variant's last workgroup may own fewer than 4)
     int lds_extra;      // PMODE 1: byte offset in the workgroup's LDS of the staged shading inputs its waves share: the jitter
                         // table (16 float2), then what lds_flags names
-    int lds_flags;      // 0 = nothing staged; bit 2: the jitter inputs are (the table, and per wave the lanes' blue-noise
-                        // values); bit 0: the light records follow the table (n_lights <= LDS_LIGHTS); bit 1: then the
+    int lds_flags;      // 0 = nothing staged; bit 2: the jitter table is; bit 3: and per wave the lanes' blue-noise values; bit 0: the light records follow the table (n_lights <= LDS_LIGHTS); bit 1: then the
                         // material records of the leaf's meshes, by mesh ORDER
     int pair_cap;       // PMODE 4: entries the LDS pair list holds (a multiple of 64, >= 64 * pair_meshes + 64)
     int lds_wave, lds_wave_bytes; // PMODE 1: byte offset of the first wave's own lists in the workgroup's LDS, and their stride

@@ -134,7 +134,7 @@ PT_DEV PairLds carve_pm1(void *base, const KParams &K, int wave) {
     l.pairs = (uint32_t *)(w + 512);
     w += 512 + (size_t)meshes * 128;
     l.bn = (const float2 *)w;
-    w += (K.lds_flags & 4) ? 64 * 8 : 0;
+    w += (K.lds_flags & 8) ? 64 * 8 : 0;
     l.count = (unsigned long long *)w;
     return l;
 }
@@ -1602,14 +1602,16 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     // registers, one wave less costs 6.5 % -- which is why the modes whose stacks fill that budget do not stage (measured:
     // showcase +9 % with 64 bytes too many).
     constexpr bool STAGED = (PMODE == 1);
-    bool lights_lds = false, mats_lds = false, jit_lds = false;
+    bool lights_lds = false, mats_lds = false, jit_lds = false, bn_lds = false;
+    constexpr int MAT_F4 = FULL ? 6 : 3; // float4 per staged material record (the simple-material kernel reads the first three)
     if (STAGED) {
         if (K.lds_flags) { // (0: the launch has no room for them)
             float2 *jit = const_cast<float2 *>(PL.jit), *bn = const_cast<float2 *>(PL.bn);
             float4 *lights = const_cast<float4 *>(PL.lights), *mats = const_cast<float4 *>(PL.mats);
             if (threadIdx.x < 16)
                 jit[threadIdx.x] = taa_table_entry(threadIdx.x);
-            if (!STREAM) { // (STREAM: a lane's entry follows its pixel, [R])
+            bn_lds = (K.lds_flags & 8) != 0;
+            if (!STREAM && bn_lds) { // (STREAM: a lane's entry follows its pixel, [R])
                 const int x0 = px(), y0 = global_row(pyl(), K.y0, K.il_period, K.il_phase);
                 bn[lane] = K.blue_noise[(y0 & 63) * 64 + (x0 & 63)];
             }
@@ -1621,8 +1623,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     lights[i] = K.lights[i];
             if (mats_lds) {
                 const int2 lf = K.tlas_leaves[~K.tlas_root_ref];
-                for (int i = threadIdx.x; i < K.pair_meshes * 6; i += 64 * WG)
-                    mats[i] = K.materials[K.tlas_mesh_ids[lf.x + i / 6] * 6 + i % 6];
+                for (int i = threadIdx.x; i < K.pair_meshes * MAT_F4; i += 64 * WG)
+                    mats[i] = K.materials[K.tlas_mesh_ids[lf.x + i / MAT_F4] * 6 + i % MAT_F4];
             }
         }
         __syncthreads(); // the workgroup's only barrier: triangles, tables and shading inputs are in place
@@ -1756,7 +1758,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     rng.v4 = (KR.rng + 5 * npix)[idx];
                     if (STAGED) {
                         asm volatile("" ::"v"(bnv.x), "v"(bnv.y)); // (the entry has arrived, whichever way the next branch goes)
-                        if (jit_lds)
+                        if (bn_lds)
                             const_cast<float2 *>(PL.bn)[lane] = bnv;
                     }
                     pxy = got;
@@ -1818,9 +1820,13 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 const float2 e = lds_ld2(PL.jit, (KA.frame_count + s) % 16);
                 tjx = e.x;
                 tjy = e.y;
-                int l = lane;
-                asm volatile("" : "+v"(l));
-                blue_noise_shift(lds_ld2(PL.bn, l), KA.frame_count + s, bnx, bny);
+                if (bn_lds) {
+                    int l = lane;
+                    asm volatile("" : "+v"(l));
+                    blue_noise_shift(lds_ld2(PL.bn, l), KA.frame_count + s, bnx, bny);
+                } else { // (samples in step: [A] runs once per sample for the whole wave -- the entry straight from the table)
+                    blue_noise_jitter(KA.blue_noise, x, y, KA.frame_count + s, bnx, bny);
+                }
             } else {
                 taa_jitter(KA.frame_count + s, tjx, tjy);
                 blue_noise_jitter(KA.blue_noise, x, y, KA.frame_count + s, bnx, bny);
@@ -1947,8 +1953,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 }
                 float4 m0, m2;
                 if (mats_lds) {
-                    m0 = lds_ld4(PL.mats, h_order * 6 + 0);
-                    m2 = lds_ld4(PL.mats, h_order * 6 + 2);
+                    m0 = lds_ld4(PL.mats, h_order * MAT_F4 + 0);
+                    m2 = lds_ld4(PL.mats, h_order * MAT_F4 + 2);
                 } else {
                     m0 = KC.materials[h.mesh * 6 + 0];
                     m2 = KC.materials[h.mesh * 6 + 2];
@@ -2041,7 +2047,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (want_shadow) {
             int mi = mats_lds ? h_order : h.mesh;
             asm volatile("" : "+v"(mi)); // (its own fetch of the material: not 22 registers live across the shadow phase)
-            const Material mat = mats_lds ? load_material<true>(PL.mats, mi) : load_material(KC2.materials, mi);
+            const Material mat = mats_lds ? load_material<true, MAT_F4>(PL.mats, mi) : load_material(KC2.materials, mi);
             const f3 V = -rd;
             const f3 bsdf = evaluateBSDF<FULL>(hit, mat, L, V);
             if (pdf_sample > 0.0f) {
@@ -2104,7 +2110,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         const unsigned long long t_pe = TS_NOW();
         // ---- [E] second half of the shading
         if (shaded) {
-            const Material mat = mats_lds ? load_material<true>(PL.mats, h_order) : load_material(KE.materials, h.mesh);
+            const Material mat = mats_lds ? load_material<true, MAT_F4>(PL.mats, h_order) : load_material(KE.materials, h.mesh);
             f3 scatter_dir = mk3(0.0f), att = mk3(0.0f);
             bool is_specular = false;
             // (the path's last vertex -- the depth limit follows: the scattered ray is never traced and the throughput never read

@@ -2118,6 +2118,16 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     pt::KParams K = make_params(c);
     K.spp = spp;
     K.max_depth = max_depth;
+    // Samples in step (path_trace_kernel [A], K.sample_sync): the lanes of a wave start a sample together, so a wave's lanes sit at the
+    // same bounce -- a first hit samples no light and the whole wave skips [C2] / [D] in that iteration, [A] runs once per sample
+    // for 64 lanes instead of every iteration for a quarter of them -- at the price of lanes that wait for the longest path of
+    // the sample.  Pays while most paths run to the depth limit: Cornell 4 bounces 1.764 -> 1.638 ms (3 bounces 1.42 -> 1.26),
+    // `many` 15.9 -> 14.8; loses once Russian roulette thins the wave (5 bounces 1.966 -> 1.980, 6: 2.10 -> 2.31, 8: 2.26 ->
+    // 2.80); scenes of short paths are indifferent once a path's last vertex costs nothing (showcase 3.90 -> 3.90; the fluid frame
+    // gains 3 %), so the depth limit alone decides.  Releasing the waiting lanes early
+    // (when few are still under way, or when many wait) was measured at every threshold and is worse than both extremes.
+    K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : (max_depth <= 4 ? 1 : 0);
+    c->sample_sync_eff = K.sample_sync;
     K.frame_count = frame_index;
     unsigned char *frame_rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
     // the stage that produces the final HDR image also tonemaps it; earlier stages skip theirs
@@ -2208,7 +2218,10 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     int pm1_wg = 1;
     if (pmode == 1) {
         const size_t shared0 = (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * (pt::PAIR_PAD * 16 + 16 + 32);
-        const size_t lights = (size_t)c->n_lights * 64, mats = (size_t)c->pair_meshes * 96;
+        const size_t lights = (size_t)c->n_lights * 64, mats = (size_t)c->pair_meshes * (full ? 96 : 48);
+        // (the lanes' blue-noise slots, 512 bytes per wave, are only worth their LDS while [A] runs in every iteration: with the
+        // samples in step it runs once per sample for the whole wave and reads the table itself -- room for the materials)
+        const bool stage_bn = K.sample_sync == 0;
         auto layout = [&](int wg, size_t budget, pt::KParams &P, bool may_stage = true) -> size_t { // bytes of the workgroup, 0 if over budget
             const size_t wave0 = 512 + (size_t)c->pair_meshes * 128 + 16;
             size_t shared = (shared0 + 15) & ~(size_t)15;
@@ -2217,10 +2230,10 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                 return 0;
             const size_t extra_at = shared;
             size_t wave = wave0;
-            if (may_stage && c->stage && shared + 128 + wg * (wave0 + 512) + (size_t)c->lds_pad <= budget) {
-                flags = 4;
+            if (may_stage && c->stage && shared + 128 + wg * (wave0 + (stage_bn ? 512 : 0)) + (size_t)c->lds_pad <= budget) {
+                flags = 4 | (stage_bn ? 8 : 0);
                 shared += 128;
-                wave += 512;
+                wave += stage_bn ? 512 : 0;
                 if ((c->stage & 1) && c->n_lights > 0 && c->n_lights <= pt::LDS_LIGHTS && shared + lights + wg * wave + (size_t)c->lds_pad <= budget) {
                     flags |= 1;
                     shared += lights;
@@ -2323,16 +2336,6 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         HIP_TRY(c, hipEventRecord(he, c->stream));
         ++c->head_n;
     }
-    // Samples in step (path_trace_kernel [A], K.sample_sync): the lanes of a wave start a sample together, so a wave's lanes sit at the
-    // same bounce -- a first hit samples no light and the whole wave skips [C2] / [D] in that iteration, [A] runs once per sample
-    // for 64 lanes instead of every iteration for a quarter of them -- at the price of lanes that wait for the longest path of
-    // the sample.  Pays while most paths run to the depth limit: Cornell 4 bounces 1.764 -> 1.638 ms (3 bounces 1.42 -> 1.26),
-    // `many` 15.9 -> 14.8; loses once Russian roulette thins the wave (5 bounces 1.966 -> 1.980, 6: 2.10 -> 2.31, 8: 2.26 ->
-    // 2.80); scenes of short paths are indifferent once a path's last vertex costs nothing (showcase 3.90 -> 3.90; the fluid frame
-    // gains 3 %), so the depth limit alone decides.  Releasing the waiting lanes early
-    // (when few are still under way, or when many wait) was measured at every threshold and is worse than both extremes.
-    K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : (max_depth <= 4 ? 1 : 0);
-    c->sample_sync_eff = K.sample_sync;
     // Lane refill (launch_trace): where it was measured to pay.  Overlapping 1080p Cornell frames 1.67 -> 1.62 ms, 8 bounces 2.12
     // -> 1.88, 4K 6.65 -> 6.27; a frame alone on the chip ends in a long drain of half-empty persistent waves (1.81 -> 1.97),
     // short pixels finish before the refill pays for itself (1 spp: 0.43 -> 0.61), and beside a post chain the persistent waves

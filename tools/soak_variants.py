@@ -25,9 +25,11 @@ for name, build, spp in (("showcase", P.scenes.showcase, 4), ("fluid", lambda s:
                          ("many", lambda s: _many_meshes(P, s, n=60), 4), ("cornell", P.scenes.cornell, 4)):
     a = frames(build, {}, 24, spp); b = frames(build, plain, 24, spp); c = frames(build, dict(pair_trace=0), 24, spp)
     d = frames(build, dict(refill=2, persist=7), 24, spp)  # (PMODE 1: persistent waves with lane refill, 1,792 of them for 32,400 tiles)
+    e = frames(build, dict(sample_sync=0), 24, spp)        # (every lane at its own pace; the default at 4 bounces keeps the samples in step)
+    g = frames(build, dict(sample_sync=0, refill=2), 24, spp)
     bad = 0
-    for f, (x, y, z, w) in enumerate(zip(a, b, c, d)):
+    for f, (x, y, z, w, u, v) in enumerate(zip(a, b, c, d, e, g)):
         for k in range(3):
-            if not (np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k]) and np.array_equal(x[k], w[k])): bad += 1
-        if not (x[3] == y[3] == z[3] == w[3]): bad += 1
-    print(name, "24 frames x 4 variants:", "IDENTICAL" if bad == 0 else f"{bad} MISMATCHES", a[-1][3])
+            if not all(np.array_equal(x[k], o[k]) for o in (y, z, w, u, v)): bad += 1
+        if not (x[3] == y[3] == z[3] == w[3] == u[3] == v[3]): bad += 1
+    print(name, "24 frames x 6 variants:", "IDENTICAL" if bad == 0 else f"{bad} MISMATCHES", a[len(a) // 2][3])

@@ -279,8 +279,36 @@ class Farm:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def measure(self, steps, warmup):
-        """W untimed frames, then exactly `steps` frames between barrier + synchronize brackets; the MAX over ranks."""
+    def _max_over_ranks(self, x):
+        if self.env["world"] == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.env["rehearse"] else "cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def ramp(self, block=10, cap=200, tol=0.02, budget_s=2.0):
+        """Clock-ramp guard: untimed frames, in blocks of `block`, until two consecutive blocks' mean frame times agree within
+        `tol` (a fresh box runs its first frames at lower clocks: 5 + 20 frames used to read 5 % slower than 40 + 100).  At most
+        `cap` frames or `budget_s` seconds; every rank takes the same decision (the MAX over ranks is compared)."""
+        n, prev, t_all = 0, None, time.perf_counter()
+        self.fence()
+        while n < cap:
+            t0 = time.perf_counter()
+            for _ in range(block):
+                self.step()
+            self.fence()
+            dt = self._max_over_ranks((time.perf_counter() - t0) / block)
+            n += block
+            done = prev is not None and abs(dt - prev) <= tol * min(dt, prev)
+            over = self._max_over_ranks(time.perf_counter() - t_all) > budget_s
+            if done or over:
+                break
+            prev = dt
+        return n
+
+    def measure(self, steps, warmup, ramp=True, time_launches=True):
+        """W untimed frames (+ the frames on which a scene settles its loop shape, + the clock-ramp guard's), then exactly
+        `steps` frames between barrier + synchronize brackets; the MAX over ranks."""
         torch, env = self.torch, self.env
         for _ in range(warmup):
             self.step()
@@ -290,6 +318,10 @@ class Farm:
         while self.tuning_frames < 16 and not self.scene.get_option("merged_decided"):
             self.step()
             self.tuning_frames += 1
+        self.ramp_frames = self.ramp() if ramp else 0
+        # events around every launch of the timed frames, on the stream the launch runs on (ptrt_launch_ms_history): overlapping
+        # frames are two launches each on auxiliary streams, and what the roofline is priced on is THOSE launches
+        self.scene.set_option("time_launches", 1 if time_launches else 0)
         self.fence()
         self.scene.stats()  # reset counters
         t0 = time.perf_counter()
@@ -302,18 +334,32 @@ class Farm:
         rays_ref = float(st["extension_rays"] + st["shadow_rays"])     # rays the reference path traces
         overlapped = bool(self.scene.get_option("pipelined"))
         refilled = bool(self.scene.get_option("refilled"))  # (PMODE 1: persistent waves whose lanes draw the next pixel)
+        split = int(self.scene.get_option("split_eff"))
         kms = self.scene.kernel_ms_history(steps)
         kernel_ms = float(kms.mean()) if len(kms) else float("nan")
+        launch = None
+        tr, tl = self.scene.launch_ms_history(steps * 4)
+        self.scene.set_option("time_launches", 0)
+        if overlapped and len(tr):
+            # the timed frames' own launches: duration of the trace kernel of each, and of what follows it on its stream (the
+            # tonemap pass of the lane-refill kernel, including its wait for places on the chip)
+            launch = dict(n=int(len(tr)), per_frame=split, ms=float(tr.mean()), ms_min=float(tr.min()), ms_max=float(tr.max()),
+                          tail_ms=float(tl.mean()))
+            kernel_ms = launch["ms"]
+        kernel_alone_ms = None
         if overlapped:
             # The timed frames overlapped on the device (ptrt_set_option "pipeline": a frame's launches follow the previous
-            # frame's and do not wait for it to drain), so the events around a frame measured the frame INTERVAL.  The
-            # roofline wants the kernel's own duration: a few more frames, untimed, each ordered behind the stream.
+            # frame's and do not wait for it to drain), so the events around a frame measured the frame INTERVAL.  For
+            # reference, beside the timed launches' own durations: a few more frames, untimed, each ONE launch ordered behind
+            # the stream -- a frame alone on the chip, which is what the rocprofv3 passes with --no-pipeline see.
             self.scene.set_option("pipeline", 0)
             for _ in range(10):
                 self.step()
             self.fence()
             k2 = self.scene.kernel_ms_history(8)
-            kernel_ms = float(k2.mean()) if len(k2) else kernel_ms
+            kernel_alone_ms = float(k2.mean()) if len(k2) else None
+            if launch is None and kernel_alone_ms is not None:
+                kernel_ms = kernel_alone_ms
             self.scene.set_option("pipeline", 1)
             self.scene.stats()
         if env["world"] > 1:
@@ -323,6 +369,7 @@ class Farm:
             self.dist.all_reduce(tsum, op=self.dist.ReduceOp.SUM)
             dt, rays, kernel_ms, rays_ref = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tsum[3])
         return dict(dt=dt, rays=rays, rays_ref=rays_ref, kernel_ms=kernel_ms, steps=steps, tuning_frames=self.tuning_frames,
+                    ramp_frames=self.ramp_frames, launch=launch, kernel_alone_ms=kernel_alone_ms,
                     overlapped=overlapped, refilled=refilled, sample_sync=int(self.scene.get_option("sample_sync_eff")),
                     pmode=self.scene.get_option("pmode"), merged_eff=self.scene.get_option("merged_eff"),
                     render_mode=self.scene.get_option("render_mode"))
@@ -343,38 +390,76 @@ def kernel_name(m):
     shape = {0: "lock-step", 1: "pairs over LDS-staged triangles", 2: "pair queue, separate shadow phase",
              3: "TLAS rounds", 4: "pair queue, shadow rays merged into the next traversal"}[m["pmode"]]
     if m.get("refilled"):
-        return (f"path_trace_kernel PMODE {m['pmode']} ({shape}; megakernel of persistent waves with lane refill) + "
-                "tonemap_tiles_kernel -- roofline.kernel_ms is the one-tile-per-wave kernel of a frame alone on the chip")
+        return (f"path_trace_kernel<.., STREAM = true> PMODE {m['pmode']} ({shape}; megakernel of persistent waves with lane refill) + "
+                "tonemap_tiles_kernel")
     return f"path_trace_kernel PMODE {m['pmode']} ({shape}; megakernel, fused tonemap)"
 
 
-def roofline_block(config_name, kernel_ms, pixels):
-    """HBM entry per the bench contract (algorithmic bytes / kernel time / peak) plus the bound that binds this path:
-    VALU issue.  Instruction counts, lane occupancy and measured HBM traffic come from the committed profile summary
-    (profiles/summarize.py -> profiles/rNN_roofline_inputs.json), the kernel time from this run's HIP events."""
-    algo_bytes = ALGO_BYTES_PER_PIXEL * pixels
+def roofline_block(config_name, m, pixels, ms_per_step):
+    """HBM entry per the bench contract -- algorithmic bytes of ONE launch of the dominant kernel / that launch's duration,
+    measured by HIP events on the stream it ran on, over the timed frames / peak -- plus the bound that binds this path: VALU
+    issue.  Instruction counts, lane occupancy and measured HBM traffic come from the committed profile summary of the kernel
+    the timed frames ran (profiles/summarize.py -> profiles/rNN_roofline_inputs.json: block `<config>_refill` for the
+    lane-refill kernel, `<config>` for the one-tile-per-wave kernel)."""
+    launch, kernel_ms = m.get("launch"), m["kernel_ms"]
+    per_frame = launch["per_frame"] if launch else 1  # launches a frame was dealt to (they run concurrently)
+    algo_bytes = ALGO_BYTES_PER_PIXEL * pixels / per_frame
     ok = kernel_ms == kernel_ms and kernel_ms > 0
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if ok else None
-    prof = {}
+    prof, key = {}, None
     try:  # the newest round's summary (profiles/summarize.py)
         import glob
         newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_roofline_inputs.json")))[-1]
-        prof = json.load(open(newest)).get(config_name, {})
+        allp = json.load(open(newest))
+        key = (config_name + "_refill") if (config_name and m.get("refilled")) else config_name
+        prof = allp.get(key, {}) if key else {}
     except Exception:
         prof = {}
-    valu = prof.get("valu_wave_instructions_per_launch")
+    valu = prof.get("valu_wave_instructions_per_launch")  # (the profile's launch covers the whole frame: --no-pipeline)
+    traffic = prof.get("hbm_bytes_per_launch")
+    # VALU issue: wave-instructions of a FRAME x 2 cycles over the time the chip spent on it -- the frame interval when frames
+    # overlap (its launches share the chip with the neighbouring frames'), the launch's duration otherwise
+    basis_ms = ms_per_step if launch else kernel_ms
     block = {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6),
-             "traffic": prof.get("hbm_bytes_per_launch"), "kernel_ms": round(kernel_ms, 4) if ok else None,
+             "traffic": None if traffic is None else round(traffic / per_frame),
+             "kernel_ms": round(kernel_ms, 4) if ok else None,
              "algorithmic_bytes_per_launch": algo_bytes,
+             "launches_per_frame": per_frame,
              "binding": "VALU issue + memory latency under divergence (SURVEY 8(d)); the HBM entry is the contract's, not the limit",
-             "kernel_ms_note": "duration of ONE launch over the whole frame, ordered behind the stream (HIP events); when "
-                               "config.frames_overlap is true the timed frames ran as two launches each that overlap the next "
-                               "frame's, and ms_per_step -- the frame interval -- is below it",
-             "valu_issue_frac": round(valu * VALU_CYCLES / (kernel_ms * 1e-3 * SIMDS * CLOCK_HZ), 4) if (valu and ok) else None,
-             "valu_wave_instructions_per_launch": valu, "lane_busy": prof.get("lane_busy"),
-             "profile": prof.get("source")}
+             "kernel_ms_note": ("mean duration of the timed frames' own trace-kernel launches (HIP events on the auxiliary stream each ran "
+                                "on, ptrt_launch_ms_history): a frame is `launches_per_frame` launches over interleaved rows of tiles "
+                                "that run concurrently with each other and with the neighbouring frames', so a launch lasts less than "
+                                "the frame interval ms_per_step and `achieved` x launches_per_frame is the device's rate")
+                               if launch else "duration of ONE launch over the whole frame, ordered behind the stream (HIP events)",
+             "valu_issue_frac": round(valu * VALU_CYCLES / (basis_ms * 1e-3 * SIMDS * CLOCK_HZ), 4) if (valu and ok) else None,
+             "valu_issue_basis": "frame interval (ms_per_step)" if launch else "kernel_ms",
+             "valu_wave_instructions_per_frame": valu, "lane_busy": prof.get("lane_busy"),
+             "profile": prof.get("source"), "profile_block": key if prof else None}
+    if launch:
+        block["launch"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in launch.items()}
+        block["frame_achieved"] = round(ALGO_BYTES_PER_PIXEL * pixels / (ms_per_step * 1e-3) / 1e9, 3)  # bytes of a frame / frame interval
+        block["frame_frac"] = round(block["frame_achieved"] / HBM_PEAK_GBS, 6)
+    if m.get("kernel_alone_ms") is not None:
+        block["kernel_alone_ms"] = round(m["kernel_alone_ms"], 4)  # one launch of the one-tile-per-wave kernel, a frame alone on the chip
     return block
+
+
+def spawn_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher: runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a child process, passes its output through
+    (rank 0 prints the one JSON line) and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free port for the rendezvous (several benches may share a host)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this image)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -414,6 +499,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="order every frame's launch behind the stream (ptrt_set_option pipeline=0): what the profile passes use, "
                          "so that a launch's duration is a frame's")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the clock-ramp guard (untimed frames until two 10-frame means agree within 2 %%)")
+    ap.add_argument("--no-time-launches", action="store_true", help="no events around the timed frames' launches (A/B of their cost)")
     ap.add_argument("--farm-serial", action="store_true", help="--farm: enqueue the parts in a row from the calling thread (A/B)")
     ap.add_argument("--rebuild", action="store_true",
                     help="fluid scene: rebuild the water BVH on the GPU every frame (ptrt_build_bvh) instead of refitting it")
@@ -434,6 +521,12 @@ def main():
             if c == cfg:
                 profile_key = name
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly (`python3 bench.py --gpus N`), not by torch.distributed.run: this process -- which has imported nothing
+        # that touches a device -- starts the N ranks as a CHILD (never exec: the box refuses an exec from a process that has
+        # initialised the GPU, and a child keeps this one free to relay), relays rank 0's line and exits with the child's code.
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import ptrt_amd as P
 
@@ -441,7 +534,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: torch.distributed.run was started with another --nproc-per-node")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render loop has no CPU path")
     # PTRT_BENCH_REHEARSE=1: dry run of the N > 1 code path on a ONE-GPU box -- every rank renders its band on
@@ -461,7 +554,7 @@ def main():
 
     W, H = cfg["width"], cfg["height"]
     farm = Farm(P, torch, dist, tilefarm, env, cfg["scene"], W, H, cfg["spp"], cfg["depth"], args=args, preset=args.preset)
-    m = farm.measure(args.steps, args.warmup)
+    m = farm.measure(args.steps, args.warmup, ramp=not args.no_ramp, time_launches=not args.no_time_launches)
     settings = farm.scene.settings()
     fluid_sources = None
     if cfg["scene"] == "fluid" and world == 1 and not args.rebuild:
@@ -471,7 +564,7 @@ def main():
         for src in ("device", "host", "commit"):
             if src != args.fluid_source:
                 farm.fluid_source = src
-                ms = farm.measure(max(4, args.steps // 2), 3)
+                ms = farm.measure(max(4, args.steps // 2), 3, ramp=False)
                 fluid_sources[src + "_ms"] = round(ms["dt"] / ms["steps"] * 1e3, 4)
         farm.fluid_source = args.fluid_source
         fluid_sources["gpu_commits, geometry_uploads"] = list(farm.scene.commitCounts())
@@ -531,7 +624,7 @@ def main():
               "metric": "Mrays/s", "value": round(m3["rays"] / m3["dt"] / 1e6, 2), "n_gpus": world, "steps": n3, "warmup": 9,
               "ms_per_step": round(m3["dt"] / n3 * 1e3, 4), "fps": round(n3 / m3["dt"], 3), "scaling": "strong",
               "rays_per_frame": round(m3["rays"] / n3), "kernel_ms_max_over_ranks": round(m3["kernel_ms"], 4),
-              "tuning_frames": m3["tuning_frames"], "kernel": kernel_name(m3)}
+              "tuning_frames": m3["tuning_frames"], "ramp_frames": m3["ramp_frames"], "kernel": kernel_name(m3)}
 
     if rank != 0:
         dist.destroy_process_group()
@@ -558,9 +651,11 @@ def main():
                                + (" +gpu-rebuild" if args.rebuild else ""), "name": args.config, "scene": cfg["scene"],
                    "width": W, "height": H, "spp": spp_used, "max_depth": depth_used,
                    "parallelism": (f"tile{world}-{layout}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
-                   "kernel": kernel_name(m), "tuning_frames": m["tuning_frames"], "library": P.library_info(),
-                   "frames_overlap": m["overlapped"], "samples_in_step": bool(m.get("sample_sync"))},
-        "roofline": roofline_block(profile_key if world == 1 else None, kernel_ms, W * rows0),
+                   "kernel": kernel_name(m), "tuning_frames": m["tuning_frames"], "ramp_frames": m["ramp_frames"],
+                   "library": P.library_info(),
+                   "frames_overlap": m["overlapped"], "samples_in_step": bool(m.get("sample_sync")),
+                   "pmode": int(m["pmode"]), "merged_eff": int(m["merged_eff"]), "lane_refill": bool(m["refilled"])},
+        "roofline": roofline_block(profile_key if world == 1 else None, m, W * rows0, ms_per_step),
     }
     if c3 is not None:
         out["configs3"] = c3

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTRT_ABI_VERSION 5 /* 2: ptrt_scene_desc gained env_rgba / env_width / env_height; 3: + ptrt_post_frame, ptrt_update_instances; 4: + ptrt_ring_*, ptrt_farm_* (additions only); 5: ptrt_stats gained shadow_rays_walked (the struct grew: rebuild callers of ptrt_get_stats) */
+#define PTRT_ABI_VERSION 6 /* 6: + ptrt_launch_ms_history (addition only); 2: ptrt_scene_desc gained env_rgba / env_width / env_height; 3: + ptrt_post_frame, ptrt_update_instances; 4: + ptrt_ring_*, ptrt_farm_* (additions only); 5: ptrt_stats gained shadow_rays_walked (the struct grew: rebuild callers of ptrt_get_stats) */
 
 enum {
     PTRT_OK = 0,
@@ -526,6 +526,10 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)
  *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9
  *   time_kernels 0|1      1 (default): two events around the trace kernel feed ptrt_kernel_ms_history / ptrt_last_kernel_ms
+ *   time_launches 0|1     1: three events around every launch of a frame that is dealt to the auxiliary streams ("pipeline"), on the
+ *                         stream the launch runs on: ptrt_launch_ms_history (default 0: six more driver calls per frame)
+ *   tm_prio 0..3          lane refill's tonemap pass: |1 on a stream of the highest priority (hipStreamCreateWithPriority) forked from
+ *                         and joined to its launch's stream, |2 its waves at s_setprio 3 (A/B: DESIGN.md 3.12)
  *   denoiser_active, motion_vectors, use_graphs 0|1 */
 int ptrt_set_option(ptrt_ctx *ctx, const char *name, long long value);
 /* Reads an option back, and -- read-only -- what the last ptrt_render launched, so that a measurement can name the kernel it
@@ -544,6 +548,15 @@ int ptrt_set_stream(ptrt_ctx *ctx, void *hip_stream);
  * HIP events on the stream the kernel ran on; at most 256 are kept.  Synchronises.  Returns
  * the number written (<= max_n) or a negative error. */
 int ptrt_kernel_ms_history(ptrt_ctx *ctx, float *out_ms, int max_n);
+
+/* Frames that overlap on the device (option "pipeline") run as `split` launches on auxiliary streams; the events of
+ * ptrt_kernel_ms_history then bracket the frame INTERVAL on the context's stream.  With option "time_launches" on, this returns
+ * the durations of the launches themselves, oldest first, over the unbroken run of such frames that ends with the last
+ * ptrt_render: trace_ms[k] = the path-trace kernel of launch k (HIP events on the stream it ran on), tail_ms[k] (may be NULL) =
+ * from its end to the end of the tonemap pass that follows it with lane refill (0 otherwise).  A frame contributes `split`
+ * entries.  Synchronises.  Returns the number written (<= max_n) or a negative error.  No counterpart in the reference (it
+ * times nothing); what bench.py's `roofline.kernel_ms` is measured with.  ABI 6. */
+int ptrt_launch_ms_history(ptrt_ctx *ctx, float *trace_ms, float *tail_ms, int max_n);
 
 /* duration in milliseconds of the last ptrt_render's path-trace kernel and
  * tonemap kernel, measured with HIP events on the context's stream

@@ -665,7 +665,11 @@ PT_DEV float pdf_ggx_reflect(f3 N, f3 V, f3 L, float roughness) {
     const float VdotH = max_(dot(V, H), 0.0f);
     const float D = distributionGGX(N, H, roughness);
     const float pdf_H = D * NdotH;
-    return pdf_H / (4.0f * VdotH + 1e-6f);
+    // (the constant through an opaque move: as a literal the vectoriser pairs `4 VdotH` with `D NdotH` into one v_pk_mul_f32 and
+    // the loop-invariant {-, 4.0} operand pair became a register pair parked in scratch across the render loop)
+    float four = 4.0f;
+    asm volatile("" : "+v"(four));
+    return pdf_H / (four * VdotH + 1e-6f);
 }
 PT_DEV float pdf_ggx_refract(f3 N, f3 V, f3 L, float roughness, float eta) {
     const float NdotV = max_(dot(N, V), 0.0f);

@@ -115,6 +115,10 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
 // wave has its own lists behind it: the rays' minima / flags, the pair list, the lanes' blue-noise values, the ray totals.
 // Layout (host: pm1_layout in ptrt_capi.hip): [tris + pads | meshtab | meshbox] [lds_extra: jit | lights | mats]
 // [lds_wave + wave * lds_wave_bytes: best 512 | pairs 128 * meshes | bn 512 (if staged) | count 16].
+// PMODE 1, per wave: the minima (512 B) and the pair list behind them are scratch of the traversal phases [B] / [D]; the
+// lane-refill kernel parks a finished pixel's six generator words there across [R] (6 x 256 B), so the list is never
+// smaller than what is left of that after the minima
+__host__ __device__ constexpr size_t pm1_pair_bytes(int meshes) { return (size_t)meshes * 128 > 1024 ? (size_t)meshes * 128 : 1024; }
 PT_DEV PairLds carve_pm1(void *base, const KParams &K, int wave) {
     PairLds l{};
     char *p = (char *)base;
@@ -132,7 +136,7 @@ PT_DEV PairLds carve_pm1(void *base, const KParams &K, int wave) {
     l.best = (unsigned long long *)w;
     l.occ = (uint32_t *)(w + 256); // (the any-hit flags take the second half of the minima's words)
     l.pairs = (uint32_t *)(w + 512);
-    w += 512 + (size_t)meshes * 128;
+    w += 512 + pm1_pair_bytes(meshes);
     l.bn = (const float2 *)w;
     w += (K.lds_flags & 8) ? 64 * 8 : 0;
     l.count = (unsigned long long *)w;
@@ -1656,8 +1660,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         wave_sync();
     }
 
-    int s = inside ? 0 : K.spp; // (STREAM: no lane has a pixel yet)
-    int bounce = 0;
+    // sample index (low half) and bounce (high half) of the lane in ONE register (ptrt_render refuses spp or max_depth beyond 32767)
+    int sb = inside ? 0 : K.spp; // (STREAM: no lane has a pixel yet)
     bool fresh = true;
     f3 ro = mk3(0.0f), rd = mk3(0.0f);
     bool ray_spec = true, prev_was_specular = true;
@@ -1688,7 +1692,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             // changes nothing in it: generator state, samples and sums are the pixel's own.
             const KParams &KR = kparams(kp0);
             const unsigned long long t_r = TS_NOW();
-            const bool idle = (s >= KR.spp) && !(MERGED && pending);
+            const bool idle = ((sb & 0xffff) >= KR.spp) && !(MERGED && pending);
             if (__builtin_amdgcn_ballot_w64(idle && (pxy >= 0 || q_open))) {
                 // Order matters for what the wave waits for: the new pixel is chosen FIRST and its blue-noise entry requested
                 // before anything else is in flight, so that the one wait of this block (the entry goes into the lane's LDS
@@ -1734,8 +1738,19 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     n_px += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wants && got >= 0));
                     q_next += asked < avail ? asked : avail;
                 }
-                // (the finished pixel's state moves to spare registers and is stored LAST: nothing waits for stores then)
-                const Rng rng_old = rng;
+                // (the finished pixel's state is stored LAST -- nothing waits for stores then --, so it has to outlive the loads
+                // of the new pixel's: the six generator words wait in the wave's traversal scratch in LDS (minima + pair list,
+                // idle between [D] and [B]; plane k at word 64 k + lane), the radiance sum in three registers.  Nine spare
+                // registers at the one point of the loop where every lane's whole path state is live were what this kernel spilled.)
+                uint32_t *park = (uint32_t *)PL.best;
+                if (old >= 0) {
+                    park[lane] = rng.d;
+                    park[64 + lane] = rng.v0;
+                    park[128 + lane] = rng.v1;
+                    park[192 + lane] = rng.v2;
+                    park[256 + lane] = rng.v3;
+                    park[320 + lane] = rng.v4;
+                }
                 const f3 avg_old = avg_color;
                 TS_LANES(22, got >= 0);
                 TS_LANES(23, true);
@@ -1763,7 +1778,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     }
                     pxy = got;
                     avg_color = mk3(0.0f);
-                    s = 0;
+                    sb = 0;
                     fresh = true;
                 } else if (old >= 0) {
                     pxy = -1;
@@ -1772,12 +1787,12 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     const uint32_t idx = (uint32_t)(old >> 16) * (uint32_t)KR.width + (uint32_t)(old & 0xffff);
                     __builtin_assume(idx < (1u << 27));
                     const size_t npix = KR.rng_plane;
-                    (KR.rng)[idx] = rng_old.d;
-                    (KR.rng + npix)[idx] = rng_old.v0;
-                    (KR.rng + 2 * npix)[idx] = rng_old.v1;
-                    (KR.rng + 3 * npix)[idx] = rng_old.v2;
-                    (KR.rng + 4 * npix)[idx] = rng_old.v3;
-                    (KR.rng + 5 * npix)[idx] = rng_old.v4;
+                    (KR.rng)[idx] = park[lane];
+                    (KR.rng + npix)[idx] = park[64 + lane];
+                    (KR.rng + 2 * npix)[idx] = park[128 + lane];
+                    (KR.rng + 3 * npix)[idx] = park[192 + lane];
+                    (KR.rng + 4 * npix)[idx] = park[256 + lane];
+                    (KR.rng + 5 * npix)[idx] = park[320 + lane];
                     // (a power-of-two sample count divides exactly by multiplication: the same bits as the division)
                     const float n = (float)KR.spp;
                     const f3 out = (KR.spp & (KR.spp - 1)) == 0 ? avg_old * (1.0f / n) : avg_old / n;
@@ -1791,9 +1806,9 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 TS_ADD(15, t_r);
         }
         const KParams &KL = kparams(kp0);
-        if (!__builtin_amdgcn_ballot_w64(s < KL.spp || (MERGED && pending)))
+        if (!__builtin_amdgcn_ballot_w64((sb & 0xffff) < KL.spp || (MERGED && pending)))
             break;
-        const bool live = s < KL.spp;
+        const bool live = (sb & 0xffff) < KL.spp;
 #ifdef PT_TRAV_STATS
         {
             const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
@@ -1817,19 +1832,19 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             const int x = px(), y = global_row(pyl(), KA.y0, KA.il_period, KA.il_phase);
             float tjx, tjy, bnx, bny;
             if (STAGED && jit_lds) {
-                const float2 e = lds_ld2(PL.jit, (KA.frame_count + s) % 16);
+                const float2 e = lds_ld2(PL.jit, (KA.frame_count + (sb & 0xffff)) % 16);
                 tjx = e.x;
                 tjy = e.y;
                 if (bn_lds) {
                     int l = lane;
                     asm volatile("" : "+v"(l));
-                    blue_noise_shift(lds_ld2(PL.bn, l), KA.frame_count + s, bnx, bny);
+                    blue_noise_shift(lds_ld2(PL.bn, l), KA.frame_count + (sb & 0xffff), bnx, bny);
                 } else { // (samples in step: [A] runs once per sample for the whole wave -- the entry straight from the table)
-                    blue_noise_jitter(KA.blue_noise, x, y, KA.frame_count + s, bnx, bny);
+                    blue_noise_jitter(KA.blue_noise, x, y, KA.frame_count + (sb & 0xffff), bnx, bny);
                 }
             } else {
-                taa_jitter(KA.frame_count + s, tjx, tjy);
-                blue_noise_jitter(KA.blue_noise, x, y, KA.frame_count + s, bnx, bny);
+                taa_jitter(KA.frame_count + (sb & 0xffff), tjx, tjy);
+                blue_noise_jitter(KA.blue_noise, x, y, KA.frame_count + (sb & 0xffff), bnx, bny);
             }
             const float jitter_x = tjx + (bnx - 0.5f) * 0.25f;
             const float jitter_y = tjy + (bny - 0.5f) * 0.25f;
@@ -1857,7 +1872,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             throughput = mk3(1.0f);
             if (!MERGED) // (PMODE 4 clears `acc` when it closes a sample: the previous one may still be open here)
                 acc = mk3(0.0f);
-            bounce = 0;
+            sb &= 0xffff; // bounce = 0
             fresh = false;
         }
 
@@ -1909,11 +1924,13 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             n_ext += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
         if (act) {
             if (h.mesh < 0) {
-                if (bounce == 0 && s == 0) { // G-buffer of the first sample's first hit (scene_kernels.cuh:181-193)
+                if (sb == 0) { // G-buffer of the first sample's first hit (scene_kernels.cuh:181-193)
                     const size_t idx = pidx(KC.width);
-                    KC.normal[idx * 3 + 0] = 0.0f;
-                    KC.normal[idx * 3 + 1] = 0.0f;
-                    KC.normal[idx * 3 + 2] = 0.0f;
+                    float zero = 0.0f; // (opaque: hoisted out of the loop, the zero TRIPLE of a three-dword store was three registers the lane-refill kernel kept in scratch)
+                    asm volatile("" : "+v"(zero));
+                    KC.normal[idx * 3 + 0] = zero;
+                    KC.normal[idx * 3 + 1] = zero;
+                    KC.normal[idx * 3 + 2] = zero;
                     KC.depth[idx] = 1e30f;
                     KC.object_id[idx] = -1;
                 }
@@ -1943,7 +1960,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 } else {
                     hit = make_surface(KC, h, ro, rd, nullptr, nullptr);
                 }
-                if (bounce == 0 && s == 0) {
+                if (sb == 0) {
                     const size_t idx = pidx(KC.width);
                     KC.normal[idx * 3 + 0] = hit.normal.x;
                     KC.normal[idx * 3 + 1] = hit.normal.y;
@@ -1965,7 +1982,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     throughput = throughput * beerLambert(absorption, hit.t);
                 }
                 if (m2.x > 0.0f || m2.y > 0.0f || m2.z > 0.0f) {
-                    if (bounce == 0 || prev_was_specular)
+                    if (sb < 0x10000 || prev_was_specular)
                         acc = acc + throughput * mk3(m2.x, m2.y, m2.z);
                 }
                 // light sample of next-event estimation (path_logic.cuh:305-382, 840)
@@ -2116,13 +2133,13 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             // (the path's last vertex -- the depth limit follows: the scattered ray is never traced and the throughput never read
             // again, so only the generator moves on, by the uniforms the reference draws here: lobe, direction, roulette.  With
             // the samples in step this is the whole wave in one iteration of max_depth.)
-            const bool last = bounce + 1 >= KE.max_depth;
+            const bool last = (sb >> 16) + 1 >= KE.max_depth;
             if (!material_scatter<FULL>(hit, mat, rd, rng, scatter_dir, att, is_specular, last)) {
                 end_path = true;
             } else {
                 prev_was_specular = is_specular;
                 bool killed = false;
-                if (bounce >= 2) { // Russian roulette (path_logic.cuh:871-880)
+                if (sb >= 0x20000) { // Russian roulette (path_logic.cuh:871-880)
                     const float p = max_(0.05f, min_(0.95f, max_(throughput.x, max_(throughput.y, throughput.z))));
                     if (rng_uniform(rng) > p)
                         killed = true;
@@ -2138,8 +2155,8 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                     ro = (dot(scatter_dir, hit.normal) > 0.0f) ? (hit.point + off) : (hit.point - off);
                     rd = scatter_dir;
                     ray_spec = is_specular;
-                    ++bounce;
-                    if (bounce >= KE.max_depth)
+                    sb += 0x10000; // ++bounce
+                    if ((sb >> 16) >= KE.max_depth)
                         end_path = true;
                 }
             }
@@ -2153,7 +2170,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 if (MERGED)
                     acc = mk3(0.0f);
             }
-            ++s;
+            ++sb; // ++s
             fresh = true;
         }
         if (PMODE == 1)
@@ -2257,7 +2274,11 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
 
 // Lane refill (path_trace_kernel<.., STREAM = true>): the fused tonemap as a pass of its own behind the launch (same tiles, same mapping, same
 // bytes): a persistent wave's pixels are not a tile's, so there is no tile epilogue to put it in.  One wave per 8x8 tile.
-__global__ __launch_bounds__(64) void tonemap_tiles_kernel(const KParams K) {
+// PRIO (option "tm_prio" | 2): the pass shares the chip with the OTHER stream's persistent waves (frames overlap); its waves are a
+// few hundred instructions each and everything behind them on their stream waits, so they take the issue slots first.
+template <bool PRIO> __global__ __launch_bounds__(64) void tonemap_tiles_kernel(const KParams K) {
+    if (PRIO)
+        __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x, tile = blockIdx.x;
     const int tx = tile % K.tiles_x;
     const int ty = K.split_n > 1 ? (tile / K.tiles_x) * K.split_n + K.split_i : tile / K.tiles_x;

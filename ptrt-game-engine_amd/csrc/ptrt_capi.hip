@@ -197,8 +197,8 @@ struct ptrt_ctx {
     // joined to its stream by events, so the caller still sees one stream).  Concurrent launches of ONE frame buy nothing
     // (Cornell 1080p 1.85 vs 1.82 ms); what they make possible is option "pipeline": frame N + 1's launches follow frame N's
     // on their own streams and do not wait for the rest of frame N to drain -- 1.81 -> 1.66 ms (see ptrt_render).
-    int split = 2, split_eff = 1, pipeline = 1;
     static constexpr int MAX_SPLIT = 4;
+    int split = 2, split_eff = 1, pipeline = 1;
     hipStream_t aux_stream[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t split_fork = nullptr, split_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
     bool heads_fresh = false;     // PMODE 3: the TLAS-leaf-order heads were gathered since the last touching entry point
@@ -223,6 +223,20 @@ struct ptrt_ctx {
     int last_pmode = 0;                  // PMODE of the last megakernel launch (ptrt_get_option "pmode")
     bool last_merged_possible = false;   // ... and whether that scene has the two loop shapes to choose from
     bool timed = false;
+    bool prev_post = false;              // the previous frame had a denoiser / bloom chain behind its trace (ptrt_render "pipeline")
+    size_t refill_counter_base = 0;      // first counter slot of the lane-refill kernel's launches (disjoint from the tile slots)
+    // option "time_launches": three events per launch of a frame dealt to the auxiliary streams -- before the trace kernel,
+    // behind it, behind the tonemap pass that follows it with lane refill -- on the stream the launch runs on, so that a
+    // measurement can state the duration of the very launches it timed (ptrt_launch_ms_history); the events around a frame on
+    // the context's stream (time_kernels) measure the frame INTERVAL once frames overlap
+    int time_launches = 0;
+    std::vector<hipEvent_t> launch_ev[MAX_SPLIT]; // 3 * EV_RING per auxiliary stream
+    unsigned char launch_timed[EV_RING] = {};     // launches of frame (launches % EV_RING) that carry events (0: none)
+    // option "tm_prio" (lane refill's tonemap pass): bit 0 = the pass runs on a stream of the highest priority, forked from
+    // and joined to the launch's stream by events; bit 1 = its waves raise their issue priority (s_setprio 3)
+    int tm_prio = 0;
+    hipStream_t tm_stream[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t tm_fork[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr}, tm_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // Presentation ring without a context (ptrt_ring_*): the CUDA-registered GL pixel-buffer object of
@@ -630,9 +644,12 @@ int pick_geom(ptrt_ctx *c) {
 
 // One 8x8 tile per 64-thread workgroup.  The frame's tile rows may be dealt to `c->split_eff` launches that run concurrently
 // on the context's stream and its auxiliary streams (forked and joined by events around them: render_split_begin / _end).
-template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams &K0, bool full, int grid, size_t lds) {
+template <int GEOM, int PMODE> int launch_trace(ptrt_ctx *c, const pt::KParams &K0, bool full, int grid, size_t lds) {
     const int n = c->split_eff > 1 ? c->split_eff : 1;
     const int tiles_y = grid / K0.tiles_x;
+    const int slot = (int)(c->launches % EV_RING);
+    const bool timed = c->time_launches && n > 1; // (one launch on the context's stream is what the frame's own events bracket)
+    c->launch_timed[slot] = 0;
     for (int i = 0; i < n; ++i) {
         pt::KParams K = K0;
         K.split_n = n;
@@ -641,6 +658,18 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
         if (g <= 0)
             continue;
         hipStream_t st = n > 1 ? c->aux_stream[i] : c->stream;
+        hipEvent_t *ev = nullptr;
+        if (timed) {
+            if (c->launch_ev[i].empty()) {
+                c->launch_ev[i].assign(3 * EV_RING, nullptr);
+                for (auto &e : c->launch_ev[i])
+                    HIP_TRY(c, hipEventCreate(&e));
+            }
+            ev = &c->launch_ev[i][3 * slot];
+            HIP_TRY(c, hipEventRecord(ev[0], st));
+            c->launch_timed[slot] = (unsigned char)(c->launch_timed[slot] | (1u << i));
+        }
+        bool launched = false;
         if constexpr (PMODE == 1) {
             if (c->refill_eff) {
                 // Lane refill: persistent waves -- as many as the chip holds at this variant's occupancy (option "persist":
@@ -648,22 +677,56 @@ template <int GEOM, int PMODE> void launch_trace(ptrt_ctx *c, const pt::KParams 
                 K.n_tiles = g;
                 K.ticket_tiles = c->ticket_tiles;
                 K.queue = c->d_queue + 2 * (n > 1 ? 1 + i : 0); // (launches that share a queue are ordered: one stream each)
+                if (K.counters) // (slots of its own: a launch of the one-tile kernel on another stream may still be adding to the tile slots)
+                    K.counters += c->refill_counter_base * pt::COUNTER_WORDS;
                 const int per_cu = c->persist > 0 ? c->persist : 4 * pt::waves_per_simd(PMODE, full, 1);
                 const int waves = std::min((g + c->ticket_tiles - 1) / c->ticket_tiles, c->n_cus * per_cu);
                 if (full)
                     hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE, 1, true>), dim3(waves), dim3(64), lds, st, K);
                 else
                     hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PMODE, 1, true>), dim3(waves), dim3(64), lds, st, K);
-                if (K.rgb8)
-                    hipLaunchKernelGGL(pt::tonemap_tiles_kernel, dim3(g), dim3(64), 0, st, K);
-                continue;
+                if (ev)
+                    HIP_TRY(c, hipEventRecord(ev[1], st));
+                if (K.rgb8) {
+                    hipStream_t ts = st;
+                    if ((c->tm_prio & 1) && n > 1) { // the pass on a stream of the highest priority, between two events of the launch's stream
+                        if (!c->tm_stream[i]) {
+                            int lo = 0, hi = 0;
+                            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                            HIP_TRY(c, hipStreamCreateWithPriority(&c->tm_stream[i], hipStreamNonBlocking, hi));
+                            HIP_TRY(c, hipEventCreateWithFlags(&c->tm_fork[i], hipEventDisableTiming));
+                            HIP_TRY(c, hipEventCreateWithFlags(&c->tm_join[i], hipEventDisableTiming));
+                        }
+                        ts = c->tm_stream[i];
+                        HIP_TRY(c, hipEventRecord(c->tm_fork[i], st));
+                        HIP_TRY(c, hipStreamWaitEvent(ts, c->tm_fork[i], 0));
+                    }
+                    if (c->tm_prio & 2)
+                        hipLaunchKernelGGL(pt::tonemap_tiles_kernel<true>, dim3(g), dim3(64), 0, ts, K);
+                    else
+                        hipLaunchKernelGGL(pt::tonemap_tiles_kernel<false>, dim3(g), dim3(64), 0, ts, K);
+                    if (ts != st) {
+                        HIP_TRY(c, hipEventRecord(c->tm_join[i], ts));
+                        HIP_TRY(c, hipStreamWaitEvent(st, c->tm_join[i], 0));
+                    }
+                }
+                if (ev)
+                    HIP_TRY(c, hipEventRecord(ev[2], st));
+                launched = true;
             }
         }
+        if (launched)
+            continue;
         if (full)
             hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, true, PMODE>), dim3(g), dim3(64), lds, st, K);
         else
             hipLaunchKernelGGL((pt::path_trace_kernel<GEOM, false, PMODE>), dim3(g), dim3(64), lds, st, K);
+        if (ev) {
+            HIP_TRY(c, hipEventRecord(ev[1], st));
+            HIP_TRY(c, hipEventRecord(ev[2], st));
+        }
     }
+    return PTRT_OK;
 }
 
 // in-wave (ray, mesh) pair compaction needs every BLAS to be one leaf and the staged
@@ -687,7 +750,7 @@ size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
                (size_t)c->stack_entries * 64 * sizeof(uint2) + (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 +
                256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES + 16;
     // staged heads (PMODE 1: and the mesh table), 16-bit pair entries, the rays' minima (whose second half holds the any-hit flags)
-    const size_t common = (size_t)c->pair_meshes * (pmode == 1 ? 48 : 32) + (size_t)c->pair_meshes * 128 + 512;
+    const size_t common = (size_t)c->pair_meshes * (pmode == 1 ? 48 : 32) + (pmode == 1 ? pt::pm1_pair_bytes(c->pair_meshes) : (size_t)c->pair_meshes * 128) + 512;
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16 + 16
                       : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16; // (+ the ray totals)
 }
@@ -1170,7 +1233,11 @@ int create_ctx(int full_w, int full_h, int tile_y0, int tile_rows, int il_period
     HIP_TRY(c, hipMalloc((void **)&c->d_rgb8, c->npix * 3));
     c->n_counter_slots = (size_t)((c->W + 7) / 8) * ((c->rows + 7) / 8); // one slot of pt::COUNTER_WORDS per 8x8-pixel workgroup
     c->n_counter_slots += 4; // the shade stage uses one slot per wave of a 256-thread grid (rounded up)
-    c->n_counter_slots += (size_t)ptrt_ctx::MAX_SPLIT * ((c->W + 7) / 8); // (lane refill: a slot per wave and launch of a split frame)
+    c->n_counter_slots += (size_t)ptrt_ctx::MAX_SPLIT * ((c->W + 7) / 8);
+    // (lane refill: a slot per persistent wave and launch of a split frame -- never more waves than tiles -- in a range of their own:
+    // consecutive overlapping frames may run the one-tile kernel and the refill kernel on different streams at the same time)
+    c->refill_counter_base = c->n_counter_slots;
+    c->n_counter_slots += (size_t)((c->W + 7) / 8) * ((c->rows + 7) / 8) + (size_t)ptrt_ctx::MAX_SPLIT * ((c->W + 7) / 8);
     HIP_TRY(c, hipMalloc((void **)&c->d_queue, 2 * (1 + ptrt_ctx::MAX_SPLIT) * sizeof(unsigned int)));
     HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, 2 * (1 + ptrt_ctx::MAX_SPLIT) * sizeof(unsigned int), c->stream));
     HIP_TRY(c, hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -1216,6 +1283,19 @@ void ptrt_destroy(ptrt_ctx *c) {
         }
         if (c->split_join[i])
             (void)hipEventDestroy(c->split_join[i]);
+    }
+    for (int i = 0; i < ptrt_ctx::MAX_SPLIT; ++i) {
+        if (c->tm_stream[i]) {
+            (void)hipStreamSynchronize(c->tm_stream[i]);
+            (void)hipStreamDestroy(c->tm_stream[i]);
+        }
+        if (c->tm_fork[i])
+            (void)hipEventDestroy(c->tm_fork[i]);
+        if (c->tm_join[i])
+            (void)hipEventDestroy(c->tm_join[i]);
+        for (hipEvent_t e : c->launch_ev[i])
+            if (e)
+                (void)hipEventDestroy(e);
     }
     if (c->split_fork)
         (void)hipEventDestroy(c->split_fork);
@@ -2109,8 +2189,8 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         return fail(c, PTRT_E_NOT_READY, "ptrt_render: %d materials for %d meshes", c->n_materials, c->n_meshes);
     if (!c->rng_ready)
         return fail(c, PTRT_E_NOT_READY, "ptrt_render: generator states not initialised (ptrt_reset_rng)");
-    if (spp < 1 || max_depth < 1)
-        return fail(c, PTRT_E_INVALID, "ptrt_render: spp=%d max_depth=%d", spp, max_depth);
+    if (spp < 1 || max_depth < 1 || spp > 32767 || max_depth > 32767) // (a lane keeps its sample index and bounce in one register's halves)
+        return fail(c, PTRT_E_INVALID, "ptrt_render: spp=%d max_depth=%d (1..32767)", spp, max_depth);
     if (frame_index < 0 || frame_index > INT_MAX - spp) // (sample s of the frame indexes the jitter table with (frame_index + s) % 16)
         return fail(c, PTRT_E_INVALID, "ptrt_render: frame_index=%d", frame_index);
     if (int rc = set_device(c))
@@ -2223,7 +2303,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         // samples in step it runs once per sample for the whole wave and reads the table itself -- room for the materials)
         const bool stage_bn = K.sample_sync == 0;
         auto layout = [&](int wg, size_t budget, pt::KParams &P, bool may_stage = true) -> size_t { // bytes of the workgroup, 0 if over budget
-            const size_t wave0 = 512 + (size_t)c->pair_meshes * 128 + 16;
+            const size_t wave0 = 512 + pt::pm1_pair_bytes(c->pair_meshes) + 16;
             size_t shared = (shared0 + 15) & ~(size_t)15;
             int flags = 0;
             if (shared + wg * wave0 + (size_t)c->lds_pad > budget)
@@ -2290,12 +2370,46 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     const bool splittable = c->pipeline && n_split > 1 && tiles_y >= 2 * n_split && !async_applicable(c) &&
                             !wavefront_applicable(c, spp, max_depth) && !(pmode == 1 && pm1_wg == 2) &&
                             !(pmode == 2 && c->lds_nodes && c->stack_entries > 0);
-    if (splittable && !c->touched && !c->escaped && !tuning && !scaled && out_rgb8 && out_is_device &&
-        out_rgb8 != c->prev_out && c->prev_stream == c->stream && c->prev_split > 0) {
+    // (a caller recording the stream into a hipGraph: the bookkeeping events below would become nodes of its graph, and a replay
+    // never passes through here -- such a frame is one ordered launch, and so is the first frame after it)
+    bool recording = false;
+    if (splittable) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess)
             (void)hipGetLastError();
-        if (cs == hipStreamCaptureStatusNone) {
+        recording = cs != hipStreamCaptureStatusNone;
+    }
+    const bool post = denoise || bloom;
+    // (the previous frame's post chain reads the HDR image and G-buffers this frame's trace would overwrite: a frame WITH a chain
+    // writes the other set, below; one without -- the chain was switched off in between -- waits for the stream instead.  A
+    // changed number of launches moves the rows between the auxiliary streams: only a one-launch frame may precede it.)
+    if (splittable && !recording && !c->touched && !c->escaped && !tuning && !scaled && out_rgb8 && out_is_device &&
+        out_rgb8 != c->prev_out && c->prev_stream == c->stream && (c->prev_split == n_split || c->prev_split == 1) &&
+        !(c->prev_post && !post)) {
+        {
+            // (the second set of HDR image and G-buffers: all four or none -- a failed allocation leaves the frame unpipelined)
+            bool alt_ok = true;
+            if (post && !c->alt_accum) {
+                float *a = nullptr, *nrm = nullptr, *d = nullptr;
+                int *o = nullptr;
+                alt_ok = hipMalloc((void **)&a, c->npix * 3 * sizeof(float)) == hipSuccess &&
+                         hipMalloc((void **)&nrm, c->npix * 3 * sizeof(float)) == hipSuccess &&
+                         hipMalloc((void **)&d, c->npix * sizeof(float)) == hipSuccess &&
+                         hipMalloc((void **)&o, c->npix * sizeof(int)) == hipSuccess;
+                if (alt_ok) {
+                    c->alt_accum = a;
+                    c->alt_normal = nrm;
+                    c->alt_depth = d;
+                    c->alt_object_id = o;
+                } else {
+                    (void)hipGetLastError();
+                    dfree(a);
+                    dfree(nrm);
+                    dfree(d);
+                    dfree(o);
+                }
+            }
+            if (alt_ok) {
             for (int i = 0; i < n_split; ++i)
                 if (!c->aux_stream[i]) {
                     HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking));
@@ -2307,15 +2421,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
                 if (c->head_ev[(c->head_n + 1) & 1])
                     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream[i], c->head_ev[(c->head_n + 1) & 1], 0));
             }
-            if (denoise || bloom) {
+            if (post) {
                 // the post chain of the previous frame may still be reading the HDR image and the G-buffers on the stream:
                 // this frame's trace writes the OTHER set (its own post chain, enqueued behind the join, reads that one)
-                if (!c->alt_accum) {
-                    HIP_TRY(c, hipMalloc((void **)&c->alt_accum, c->npix * 3 * sizeof(float)));
-                    HIP_TRY(c, hipMalloc((void **)&c->alt_normal, c->npix * 3 * sizeof(float)));
-                    HIP_TRY(c, hipMalloc((void **)&c->alt_depth, c->npix * sizeof(float)));
-                    HIP_TRY(c, hipMalloc((void **)&c->alt_object_id, c->npix * sizeof(int)));
-                }
                 std::swap(c->d_accum, c->alt_accum);
                 std::swap(c->d_normal, c->alt_normal);
                 std::swap(c->d_depth, c->alt_depth);
@@ -2327,9 +2435,10 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
             }
             c->split_eff = n_split;
             c->pipelined_last = true;
+            }
         }
     }
-    if (splittable) { // the stream's head at this call, for the NEXT frame
+    if (splittable && !recording) { // the stream's head at this call, for the NEXT frame
         hipEvent_t &he = c->head_ev[c->head_n & 1];
         if (!he)
             HIP_TRY(c, hipEventCreateWithFlags(&he, hipEventDisableTiming));
@@ -2363,9 +2472,9 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         hipLaunchKernelGGL((pt::path_trace_kernel<0, false, 1, 2>), dim3((grid + 1) / 2), dim3(128), lds_main, c->stream, K);
     }
     else if (pmode == 1)
-        launch_trace<0, 1>(c, K, full, grid, lds_main);
+        { if (int rc = launch_trace<0, 1>(c, K, full, grid, lds_main)) return rc; }
     else if (pmode == 4)
-        launch_trace<1, 4>(c, K, full, grid, lds_main);
+        { if (int rc = launch_trace<1, 4>(c, K, full, grid, lds_main)) return rc; }
     else if (pmode == 2 && c->lds_nodes && c->stack_entries > 0) {
         // four tiles per workgroup, one LDS copy of the mesh heads and of the BLAS top levels (north star: "BVH nodes
         // ... staged in LDS")
@@ -2380,22 +2489,25 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         else
             hipLaunchKernelGGL((pt::path_trace_kernel<1, false, 2, 4>), dim3((grid + 3) / 4), dim3(256), lds4, c->stream, K);
     } else if (pmode == 2)
-        launch_trace<1, 2>(c, K, full, grid, lds_main);
+        { if (int rc = launch_trace<1, 2>(c, K, full, grid, lds_main)) return rc; }
     else if (pmode == 3)
-        launch_trace<2, 3>(c, K, full, grid, lds_main);
+        { if (int rc = launch_trace<2, 3>(c, K, full, grid, lds_main)) return rc; }
     else if (geom == 0)
-        launch_trace<0, 0>(c, K, full, grid, lds);
+        { if (int rc = launch_trace<0, 0>(c, K, full, grid, lds)) return rc; }
     else if (geom == 1)
-        launch_trace<1, 0>(c, K, full, grid, lds);
+        { if (int rc = launch_trace<1, 0>(c, K, full, grid, lds)) return rc; }
     else
-        launch_trace<2, 0>(c, K, full, grid, lds);
+        { if (int rc = launch_trace<2, 0>(c, K, full, grid, lds)) return rc; }
     HIP_TRY(c, hipGetLastError());
     for (int i = 0; c->split_eff > 1 && i < c->split_eff; ++i) { // join: what follows on the context's stream follows every launch
         HIP_TRY(c, hipEventRecord(c->split_join[i], c->aux_stream[i]));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_join[i], 0));
     }
     c->prev_split = 0;
-    if (c->split_eff > 1) {
+    c->prev_post = post;
+    if (recording) {
+        c->touched = true; // (what a replayed graph does to the buffers is not this call's to know: the next frame waits for the stream)
+    } else if (c->split_eff > 1) {
         c->prev_split = c->split_eff;
     } else if (splittable && c->last_mode == 0) { // one launch on the stream: the point the next frame's launches may follow
         if (!c->split_fork)
@@ -2714,6 +2826,7 @@ int ptrt_set_stream(ptrt_ctx *c, void *hip_stream) {
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     c->launches = 0;
     c->timed = false;
+    memset(c->launch_timed, 0, sizeof c->launch_timed);
     return PTRT_OK;
 }
 
@@ -2733,6 +2846,42 @@ int ptrt_kernel_ms_history(ptrt_ctx *c, float *out_ms, int max_n) {
         HIP_TRY(c, hipEventElapsedTime(&out_ms[i], c->ev_ring[2 * slot], c->ev_ring[2 * slot + 1]));
     }
     return (int)n;
+}
+
+// Durations of the LAUNCHES of the last frames that were dealt to the auxiliary streams with option "time_launches" on, oldest
+// first: trace_ms[k] = the path-trace kernel of launch k, tail_ms[k] = from its end to the end of the tonemap pass behind it
+// (lane refill; 0 otherwise).  A frame of `split` launches contributes `split` entries.  Waits for the stream.
+int ptrt_launch_ms_history(ptrt_ctx *c, float *trace_ms, float *tail_ms, int max_n) {
+    if (!ctx_live(c) || !trace_ms || max_n < 0)
+        return fail(c, PTRT_E_INVALID, "ptrt_launch_ms_history: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned long long frames = c->launches < (unsigned long long)EV_RING ? c->launches : EV_RING;
+    // newest first, then reversed into the caller's arrays
+    std::vector<float> a, b;
+    for (unsigned long long f = 0; f < frames && (int)a.size() < max_n; ++f) {
+        const int slot = (int)((c->launches - 1 - f) % EV_RING);
+        if (!c->launch_timed[slot])
+            break; // (the run of timed frames ends here)
+        for (int i = ptrt_ctx::MAX_SPLIT - 1; i >= 0 && (int)a.size() < max_n; --i)
+            if ((c->launch_timed[slot] >> i) & 1) {
+                float t = 0.0f, u = 0.0f;
+                hipEvent_t *ev = &c->launch_ev[i][3 * slot];
+                HIP_TRY(c, hipEventSynchronize(ev[2]));
+                HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[1]));
+                HIP_TRY(c, hipEventElapsedTime(&u, ev[1], ev[2]));
+                a.push_back(t);
+                b.push_back(u);
+            }
+    }
+    const int n = (int)a.size();
+    for (int k = 0; k < n; ++k) {
+        trace_ms[k] = a[n - 1 - k];
+        if (tail_ms)
+            tail_ms[k] = b[n - 1 - k];
+    }
+    return n;
 }
 
 void *ptrt_device_buffer(ptrt_ctx *c, int kind) {
@@ -2919,6 +3068,10 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
     }
     else if (n == "time_kernels") // 0: no start / stop events around the trace kernel (two driver calls per frame; ptrt_kernel_ms_history then has nothing)
         c->time_kernels = value ? 1 : 0;
+    else if (n == "time_launches") // 1: events around every launch of a frame dealt to the auxiliary streams (ptrt_launch_ms_history)
+        c->time_launches = value ? 1 : 0;
+    else if (n == "tm_prio") // lane refill's tonemap pass: | 1 on a stream of the highest priority, | 2 its waves at s_setprio 3
+        c->tm_prio = (int)(value & 3);
     else if (n == "pipeline") // 1 (default): consecutive frames may overlap on the device when that is safe (ptrt_render); 0: never
         c->pipeline = value ? 1 : 0;
     else if (n == "persist")
@@ -2979,7 +3132,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"persist", c->persist}, {"refill", c->refill}, {"sample_sync", c->sample_sync}, {"sample_sync_eff", c->sample_sync_eff}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"time_launches", c->time_launches}, {"tm_prio", c->tm_prio}, {"persist", c->persist}, {"refill", c->refill}, {"sample_sync", c->sample_sync}, {"sample_sync_eff", c->sample_sync_eff}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

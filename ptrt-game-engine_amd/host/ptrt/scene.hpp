@@ -1005,10 +1005,21 @@ class Scene {
 
     // host half of updateAccelerationStructures (scene.cuh:596-743): rebuild dirty
     // BLAS, refresh descriptors, detect moved instances, rebuild the TLAS
-    void prepareHostStructures() {
+    // `forRead`: somebody is about to read the host trees (flatten()).  A commit that stays on the GPU does not: the host copy
+    // of a tree the GPU refitted / rebuilt is brought up to date only when it is read or uploaded again -- before a full upload,
+    // for a TLAS with inner nodes (rebuilt on the host over the new boxes), when an instance moved (its world box comes from
+    // the tree's root) -- not on every commit (a CPU refit of the whole tree, and after a GPU rebuild a read-back that waits
+    // for the stream).
+    void prepareHostStructures(bool forRead = true) {
         if (meshes.empty())
             return;
-        const bool synced = syncHostTrees(); // (trees the GPU refitted / rebuilt since the host last looked)
+        bool need_trees = forRead || geometryDirty || flatMeshes.size() != meshes.size() || h_tlasNodes.size() != 1;
+        for (size_t i = 0; i < meshes.size() && !need_trees; ++i) {
+            const Mesh *m = meshes[i].get();
+            need_trees = m->vertsDirty || m->bvhDirty || m->bvhNodes.empty() || m->transform.dirty ||
+                         std::memcmp(&lastWorld[i], &m->transform.worldMatrix, sizeof(mat4)) != 0;
+        }
+        const bool synced = need_trees && syncHostTrees(); // (trees the GPU refitted / rebuilt since the host last looked)
         bool tlas_dirty = h_tlasNodes.empty() || synced;
         if (flatMeshes.size() != meshes.size()) {
             flatMeshes.assign(meshes.size(), ptrt_mesh_desc{});
@@ -1173,7 +1184,7 @@ class Scene {
             return;
         }
         commitOnGpu();
-        prepareHostStructures();
+        prepareHostStructures(false);
         if (geometryDirty) {
             check(ptrt_upload_geometry(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,
                                        flat.tlas_mesh_indices, flat.tlas_index_count),

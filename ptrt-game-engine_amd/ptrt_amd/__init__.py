@@ -149,6 +149,7 @@ _sig("ptrt_get_option", C.c_int, _vp, C.c_char_p, C.POINTER(C.c_longlong))
 _sig("ptrt_last_kernel_ms", C.c_int, _vp, _fp, _fp)
 _sig("ptrt_set_stream", C.c_int, _vp, _vp)
 _sig("ptrt_kernel_ms_history", C.c_int, _vp, _fp, C.c_int)
+_sig("ptrt_launch_ms_history", C.c_int, _vp, _fp, _fp, C.c_int)
 _sig("ptrt_debug_detmath", C.c_int, _vp, C.c_int, _fp, _fp, C.c_int, _fp)
 
 # ---- Scene mirror (csrc/ptrt_host_capi.cpp) ---------------------------------------------
@@ -611,6 +612,14 @@ class Scene:
         if n < 0:
             raise PtrtError(lib.ptrt_last_error(self.ctx).decode())
         return out[:n]
+
+    def launch_ms_history(self, max_n=1024):
+        """(trace_ms, tail_ms) of the launches of the last overlapping frames (option time_launches), oldest first."""
+        a, b = np.zeros(max_n, dtype=np.float32), np.zeros(max_n, dtype=np.float32)
+        n = lib.ptrt_launch_ms_history(self.ctx, _fptr(a), _fptr(b), max_n)
+        if n < 0:
+            raise PtrtError(lib.ptrt_last_error(self.ctx).decode())
+        return a[:n], b[:n]
 
     def trace_rays(self, origins, directions):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

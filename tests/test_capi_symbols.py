@@ -27,7 +27,7 @@ def test_struct_layouts_match_reference_sizes(P):
     assert ctypes.sizeof(P.Vec3) == 12 and ctypes.sizeof(P.BvhNode) == 40 and ctypes.sizeof(P.Tri) == 12
     assert ctypes.sizeof(P.Light) == 60 and ctypes.sizeof(P.Hit) == 64
     assert P.Light.position.offset == 4 and P.Light.color.offset == 28 and P.Light.radius.offset == 56
-    assert P.lib.ptrt_abi_version() == 5
+    assert P.lib.ptrt_abi_version() == 6
 
 
 def test_no_cpu_fallback(P):

@@ -277,6 +277,142 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
     assert on[1][0].any()
 
 
+def test_post_chain_switched_off_between_overlapping_frames(P):
+    """a frame WITHOUT a post chain must not overlap a predecessor WITH one -- that frame's denoiser / bloom still
+    reads the HDR image and G-buffers the trace would overwrite (the application toggles perfSettings.enableBloom / enableDenoiser,
+    which reach the back end through host-only entry points).  Such a frame waits for the stream; the frames before and after
+    equal the ones rendered with pipeline = 0."""
+    import torch
+    W, H = 640, 360
+
+    def run(pipeline):
+        s = P.Scene(W, H)
+        P.scenes.cornell(s)
+        s.setPerfSamplesPerPixel(2)
+        s.setMaxBounceDepth(3)
+        s.setDenoiserEnabled(True)
+        s.setBloomEnabled(True)
+        s.initBlueNoise()
+        s.uploadToGPU()
+        s.set_option("pipeline", pipeline)
+        tgt = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        flags, frames = [], []
+        for f in range(9):
+            if f == 4:  # the application switches the chain off ...
+                s.setDenoiserEnabled(False)
+                s.setBloomEnabled(False)
+            if f == 7:  # ... and on again
+                s.setDenoiserEnabled(True)
+                s.setBloomEnabled(True)
+            s.render_to_device(tgt[f & 1].data_ptr())
+            flags.append(s.get_option("pipelined"))
+            if f in (3, 4, 5, 8):
+                torch.cuda.synchronize()
+                frames.append(tgt[f & 1].cpu().numpy().copy())
+        s.sync()
+        frames.append(s.read(P.BUF_ACCUM))
+        frames.append(s.read(P.BUF_RNG))
+        s.close()
+        return flags, frames
+
+    flags, on = run(1)
+    _, off = run(0)
+    # frame 4 (the first without a chain) waits for frame 3's chain; 5 and 6 overlap again; a frame WITH a chain may follow one
+    # without (it writes the other set and nothing reads the current one behind the fused tonemap)
+    assert flags[1:4] == [1, 1, 1] and flags[4] == 0 and flags[5:7] == [1, 1] and flags[7] == 1, flags
+    for a, b in zip(on, off):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_render_recorded_into_a_graph_then_rendered_directly(P):
+    """while the caller records the stream into a hipGraph, ptrt_render issues ONE ordered launch and records none
+    of its pipelining bookkeeping events into the caller's graph; the first frame after the recording waits for the stream
+    (a replay never passes through ptrt_render).  The replayed frame and the direct frame after it are the frames of a plain run."""
+    import torch
+    W, H = 320, 200
+
+    def scene():
+        s = P.Scene(W, H)
+        P.scenes.cornell(s)
+        s.setPerfSamplesPerPixel(2)
+        s.setMaxBounceDepth(3)
+        s.setDenoiserEnabled(False)
+        s.setBloomEnabled(False)
+        s.initBlueNoise()
+        s.uploadToGPU()
+        return s
+
+    ref = scene()
+    plain = []
+    t = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    for f in range(3):
+        ref.render_to_device(t.data_ptr())
+        torch.cuda.synchronize()
+        plain.append(t.cpu().numpy().copy())
+    ref_rng = ref.read(P.BUF_RNG)
+    ref.close()
+
+    s = scene()
+    st = torch.cuda.Stream()
+    s.set_stream(st.cuda_stream)
+    tgt = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    s.render_to_device(tgt[0].data_ptr())  # frame 0, direct
+    st.synchronize()
+    assert np.array_equal(tgt[0].cpu().numpy(), plain[0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+        s.render_to_device(tgt[1].data_ptr())  # frame 1: recorded, not run
+        assert s.get_option("pipelined") == 0 and s.get_option("split_eff") == 1
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(tgt[1].cpu().numpy(), plain[1])
+    s.render_to_device(tgt[0].data_ptr())  # frame 2, direct, into the other target: must not overlap anything
+    assert s.get_option("pipelined") == 0
+    s.render_to_device(tgt[1].data_ptr())  # ... and from here on frames overlap again
+    assert s.get_option("pipelined") == 1
+    st.synchronize()
+    s.set_stream(0)
+    del g
+    # (frame 2 went into tgt[0]; frame 3 into tgt[1])
+    assert np.array_equal(tgt[0].cpu().numpy(), plain[2])
+    s.close()
+    assert ref_rng.shape[0] == W * H
+
+
+def test_launch_durations_of_overlapping_frames(P):
+    """ptrt_launch_ms_history (ABI 6): with option time_launches the launches of frames that overlap carry their own events, on
+    the auxiliary stream each runs on -- `split` entries per frame, the trace kernel's duration and (lane refill) the tonemap
+    pass behind it; frames that are one launch on the stream have none."""
+    import torch
+    W, H = 1920, 1080
+    s = P.Scene(W, H)
+    P.scenes.cornell(s)
+    s.setPerfSamplesPerPixel(4)
+    s.setMaxBounceDepth(4)
+    s.setDenoiserEnabled(False)
+    s.setBloomEnabled(False)
+    s.initBlueNoise()
+    s.uploadToGPU()
+    tgt = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    for f in range(3):
+        s.render_to_device(tgt[f & 1].data_ptr())
+    a, b = s.launch_ms_history()
+    assert len(a) == 0  # (option off)
+    s.set_option("time_launches", 1)
+    for f in range(3, 9):
+        s.render_to_device(tgt[f & 1].data_ptr())
+        assert s.get_option("pipelined") == 1 and s.get_option("refilled") == 1
+    a, b = s.launch_ms_history()
+    assert len(a) == 12 and len(b) == 12 and (a > 0.05).all() and (a < 50).all() and (b > 0).all()
+    k = s.kernel_ms_history(6)
+    assert len(k) == 6
+    s.set_option("pipeline", 0)
+    s.render_to_device(tgt[1].data_ptr())
+    a, b = s.launch_ms_history()
+    assert len(a) == 0  # (the run of timed overlapping frames ended)
+    s.close()
+
+
 def test_lane_refill_is_chosen_where_it_pays(P):
     """ptrt_render's rule for the lane-refill kernel (option "refill" = 1, the default): PMODE 1 frames that overlap
     their predecessor, with the simple materials, no post chain, at least 16 sample-bounces per pixel and at least two tiles

@@ -286,24 +286,24 @@ class Farm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t[0])
 
-    def ramp(self, block=10, cap=200, tol=0.02, budget_s=2.0):
-        """Clock-ramp guard: untimed frames, in blocks of `block`, until two consecutive blocks' mean frame times agree within
-        `tol` (a fresh box runs its first frames at lower clocks: 5 + 20 frames used to read 5 % slower than 40 + 100).  At most
-        `cap` frames or `budget_s` seconds; every rank takes the same decision (the MAX over ranks is compared)."""
-        n, prev, t_all = 0, None, time.perf_counter()
+    def ramp(self, block=10, cap=300, tol=0.01, budget_s=2.0):
+        """Clock-ramp guard: untimed frames, in blocks of `block`, until THREE consecutive blocks' mean frame times agree within
+        `tol` (a fresh box runs its first frames at lower clocks and the ramp takes tens of milliseconds: 5 + 20 frames used to
+        read 5 % slower than 40 + 100).  At most `cap` frames or `budget_s` seconds; every rank takes the same decision (the MAX
+        over ranks is compared)."""
+        n, hist, t_all = 0, [], time.perf_counter()
         self.fence()
         while n < cap:
             t0 = time.perf_counter()
             for _ in range(block):
                 self.step()
             self.fence()
-            dt = self._max_over_ranks((time.perf_counter() - t0) / block)
+            hist.append(self._max_over_ranks((time.perf_counter() - t0) / block))
             n += block
-            done = prev is not None and abs(dt - prev) <= tol * min(dt, prev)
+            done = len(hist) >= 3 and max(hist[-3:]) - min(hist[-3:]) <= tol * min(hist[-3:])
             over = self._max_over_ranks(time.perf_counter() - t_all) > budget_s
             if done or over:
                 break
-            prev = dt
         return n
 
     def measure(self, steps, warmup, ramp=True, time_launches=True):

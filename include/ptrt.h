@@ -481,6 +481,13 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   pair_trace 0|1        (ray, mesh) pair compaction                  pair_split 0|1  lanes per pair in partial batches
  *   fetch_min 0..64       idle lanes before the pair queue refills     leaf_pairs 0|1  compacted leaf phase
  *   leaf_min 1..64        lanes waiting at a leaf that end the descent steal 0..64     shadow-ray subtree stealing
+ *   csteal 0..64          PMODE 2 closest hit: verified subtree stealing (2).  Once the pair queue is empty an idle lane takes the
+ *                         BOTTOM entry of a busy walk's stack -- what that walk would visit last -- with a copy of its ray and limit,
+ *                         walks it and merges what it finds; the node loop yields every `csteal` steps while lanes idle.  A thief's hit
+ *                         closer than its own leaf box's entry, or two walks of one (ray, mesh) pair reporting the same distance, mark
+ *                         the ray, which is then traced again without stealing: same bits.  csteal_min: node steps a
+ *                         walk must have taken before it is stolen from (0); csteal_follow 0|1: a thief keeps taking its victim's
+ *                         limit (1); csteal_leaf_min 1..64: leaf_min of a stealing phase (32).  0: off (showcase 3.60 -> 3.33 ms).
  *   lds_nodes 0|1         PMODE 2 in 256-thread workgroups sharing an LDS copy of the BLAS top levels
  *   merged -1|0|1         one traversal per loop iteration: a light sample's shadow ray rides with the next extension ray;
  *                         -1 (default): both shapes (equal bit for bit) take turns over a scene's frames 4-9, three samples

@@ -80,6 +80,10 @@ struct KParams {
     int tlas_any_rounds; // PMODE 3 shadow rays: 1 = one TLAS leaf per ray and fill (more than 1024 meshes, or option tlas_rounds)
     int pair_split;     // PMODE 1: a batch that does not fill the wave may give each pair several lanes
     int steal;          // PMODE 2 any-hit: 0 off; n > 0: idle lanes steal subtrees, node loop yields every n steps
+    int csteal;         // PMODE 2 closest hit: 0 off; n > 0: verified subtree stealing (run_closest_queue), node loop yields every n steps
+    int csteal_min;     // ... node steps a walk must have taken before its stack may be stolen from
+    int csteal_follow;  // ... 1: a thief keeps taking its victim's limit while that walk lasts
+    int csteal_leaf_min; // ... lanes waiting at a leaf that end the node loop of a stealing closest-hit phase (leaf_min of the others)
     int leaf_min;       // PMODE 2: lanes waiting at a leaf that end the node loop (64 = all of them)
     int leaf_pairs;     // PMODE 2: leaf phase as compacted (lane, triangle) pairs
     int fetch_min;      // PMODE 2: idle lanes before the wave refills from the pair list (0 = static 64-pair batches)

@@ -307,7 +307,7 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
     ts.v[1] = lane == 0 ? (unsigned)P : 0u;
 #endif
     TS_ADD(8, t_run);
-    ts.flush(0, lane);
+    ts.flush(0, lane, L.stat_bounce);
 }
 
 // extension ray (closest hit -> h) and parked shadow ray (any hit -> occluded) of every lane in one traversal

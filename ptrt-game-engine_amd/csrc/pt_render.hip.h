@@ -41,6 +41,7 @@ namespace pt {
 struct CycleAcc;
 struct PairLds {
     CycleAcc *cyc;            // (stats build: the kernel's cycle accumulator)
+    int stat_bounce;          // (stats build: bounce of the rays of this traversal -- wave-uniform with the samples in step)
     float4 *tris;             // pair_tri_slots * 3
     int4 *meshtab;            // per mesh order: {first slot, count, flags, mesh id}
     float4 *meshbox;          // per mesh order: {bmin, root ref}, {bmax, flags}: the mesh record's head, staged once
@@ -59,6 +60,7 @@ struct PairLds {
     const float2 *bn;         // 64: the lanes' blue-noise values
     const float4 *lights;     // the scene's light records (4 float4 each) when at most LDS_LIGHTS of them
     const float4 *mats;       // PMODE 1: material records (6 float4) of the leaf's meshes by mesh order
+    unsigned long long *dirty; // PMODE 2, closest-hit stealing: bit r = ray r has to be traced again without it (run_closest_queue); or NULL
     unsigned long long *count; // one-wave workgroups: [0] {extension rays, shadow rays << 32} of the wave so far, [1] light
                                // samples whose value was exactly zero (counted in [0], not walked)
 };
@@ -107,6 +109,7 @@ PT_DEV PairLds carve_pair_lds(void *base, int tri_slots, int meshes, int stack_e
     p += LEAF_PAIR_BYTES - 512;
     // the wave's ray totals (path_trace_kernel): PMODE 1 keeps them in the spare bytes behind its last mesh's packets
     l.count = tri_slots ? (unsigned long long *)(l.tris + tri_slots * 3 + (meshes - 1) * PAIR_PAD) : (unsigned long long *)p;
+    l.dirty = tri_slots ? nullptr : (unsigned long long *)p + 2;
     return l;
 }
 
@@ -179,6 +182,7 @@ PT_DEV PairLds carve_pair_lds_wg(void *base, int wave, int meshes, int stack_ent
 // wave is in each loop of the PMODE 2 traversals.  [0..7] closest, [8..15] any-hit:
 // calls, pairs, node wave-iterations, node lane-steps, leaf phases, triangle wave-iterations,
 // triangle lane-tests, outer iterations; [16] persistent-loop iterations, [17] live lanes in them.
+__device__ unsigned long long g_trav_bounce[64]; // the traversal counters [0..15] once more, split by the rays' bounce: [bounce 0..3][16]
 __device__ unsigned long long g_trav_stats[32]; // [0..7] closest, [8..15] any-hit, [16..17] loop, [18..23] lanes per phase (TS_LANES), [24..31] cycles (CycleAcc)
 // -DPT_MARKS: "; MARK x" comments in the ISA at the phase boundaries of path_trace_kernel (tools/asm_phases.py counts the
 // instructions between them)
@@ -195,16 +199,31 @@ struct TravStats {
             ++v[i];
     }
     PT_DEV void lanes(int i) { ++v[i]; }
-    PT_DEV void flush(int base, int lane) {
+    PT_DEV void flush(int base, int lane, int bounce = -1) {
         for (int i = 0; i < 8; ++i) {
             unsigned a = v[i];
             for (int off = 32; off > 0; off >>= 1)
                 a += __shfl_xor(a, off);
-            if (lane == 0 && a)
+            if (lane == 0 && a) {
                 atomicAdd(&g_trav_stats[base + i], (unsigned long long)a);
+                if (bounce >= 0)
+                    atomicAdd(&g_trav_bounce[(bounce < 3 ? bounce : 3) * 16 + base + i], (unsigned long long)a);
+            }
         }
     }
 };
+__device__ unsigned long long g_trav_dbg[4 * 256 + 1 + 8]; // 256 records, their count, event counters [1025 + k]
+#define TS_DBG(a, b, c, d)                                                                                                \
+    do {                                                                                                                 \
+        const unsigned long long i_ = atomicAdd(&g_trav_dbg[1024], 1ull);                                                \
+        if (i_ < 256) {                                                                                                  \
+            g_trav_dbg[4 * i_] = (a);                                                                                    \
+            g_trav_dbg[4 * i_ + 1] = (b);                                                                                \
+            g_trav_dbg[4 * i_ + 2] = (c);                                                                                \
+            g_trav_dbg[4 * i_ + 3] = (d);                                                                                \
+        }                                                                                                                \
+    } while (0)
+#define TS_EVENT(slot) atomicAdd(&g_trav_dbg[1025 + (slot)], 1ull) // (events: 0 subtrees stolen, 1 thief hits in front of their leaf box, 2 equal distances of two walks of a pair, 3 rays traced again)
 #define TS_WAVE(i) ts.wave(i, lane)
 #define TS_LANE(i) ts.lanes(i)
 // wave-level cycle accounting (s_memtime), accumulated in scalar registers and flushed once per wave at kernel end
@@ -229,8 +248,10 @@ struct CycleAcc {
 #define TS_ADDL(slot, t) (L.cyc->c[(slot) - 8] += __builtin_readcyclecounter() - (t))
 #else
 struct TravStats {
-    PT_DEV void flush(int, int) {}
+    PT_DEV void flush(int, int, int = -1) {}
 };
+#define TS_EVENT(slot)
+#define TS_DBG(a, b, c, d)
 #define TS_WAVE(i)
 #define TS_LANE(i)
 struct CycleAcc {
@@ -588,23 +609,42 @@ PT_DEV bool descend2_any(const float4 *__restrict__ nodes2, LdsStack stk, int &s
 }
 
 // drains the pair queue [0, P): afterwards L.best[r] = min over ray r's pairs of {t bits, order << 24 | slot}
-template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
+//
+// STEAL (option "csteal", PMODE 2): closest-hit subtree stealing WITH VERIFICATION.  A closest-hit phase lasts as long as its
+// longest walk -- secondary rays: ~12 node steps per pair, 38-45 wave-iterations per phase at 13-26 % busy lanes
+// (profiles/r04_lane_occupancy.txt, by bounce) -- and the long walks are the ones that find nothing to cull with.  Once the
+// queue is empty an idle lane takes the BOTTOM entry S of a busy lane's stack with a copy of its ray and of its limit at that
+// moment, walks it with its own stack and merges what it finds like a pair of its own.  Why the bits stay:
+//  * the bottom entry is what the owner's depth-first walk would visit LAST, so everything the owner still does is the
+//    reference's walk with the reference's limits; the reference then enters S with the owner's FINAL limit b (or culls it);
+//  * the thief walks S with a limit a >= b (limits only shrink).  As long as every hit a thief accepts lies at or beyond the
+//    entry distance of its own leaf box (child boxes lie inside their parents' and the slab arithmetic is monotone, so that
+//    is the largest entry distance on its path), the thief's limit stays >= the reference's at every step, it visits a
+//    superset of the reference's nodes in the same order, and its closest hit -- if below b -- is the reference's;
+//  * the slab test is NOT conservative w.r.t. the triangle test (E3): a thief that accepts a hit closer than its leaf box's
+//    entry, and two walks of one (ray, mesh) pair that report the same distance (the reference keeps the one it visits
+//    first), mark the ray in L.dirty[0] instead, and the caller traces marked rays again without stealing.
+// Victims must have taken K.csteal_min node steps (short walks are not worth a thief: what they leave at the bottom of the
+// stack is what their next hit culls).
+template <int GEN, bool STEAL = false> PT_DEV void run_closest_queue(const KParams &K, const PairLds &L, int lane, int P, f3 o, f3 d) {
     LdsStack stk{L.stack + lane};
     int next = 0;
-    bool busy = false, active = false, xf = false;
-    int cur = 0, sp = 0, r = 0, oi = 0, sb = -1, rootref = 0;
-    float dirScale = 1.0f, tb = T_FAR;
+    bool busy = false, active = false, xf = false, thief = false;
+    int cur = 0, sp = 0, bot = 0, r = 0, oi = 0, sb = -1, rootref = 0, nsteps = 0;
+    int gen = 0, vic = 0; // STEAL: walks this lane has begun; a thief's victim: lane | that lane's count at the theft << 8
+    float dirScale = 1.0f, tb = T_FAR, tcur = 0.0f; // tcur: entry distance of the box of `cur` (STEAL: the thieves' acceptance test)
     RayO pr = make_ray(mk3(0.0f), mk3(0.0f, 0.0f, 1.0f));
     TravStats ts;
     auto pop = [&]() {
         active = false;
-        while (sp > 0) {
+        while (sp > (STEAL ? bot : 0)) {
             --sp;
             int ref;
             float tE;
             stk.pop(sp, ref, tE);
             if (tE < tb) {
                 cur = ref;
+                tcur = tE;
                 active = true;
                 break;
             }
@@ -631,7 +671,10 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
                 pr = make_ray(po, pd);
                 xf = (mt.z & 1) != 0;
                 cur = rootref = mt.x;
-                sp = 0;
+                sp = bot = 0;
+                nsteps = 0;
+                thief = false;
+                ++gen;
                 tb = T_FAR;
                 sb = -1;
                 busy = active = true;
@@ -640,20 +683,93 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
         }
         if (!__builtin_amdgcn_ballot_w64(busy))
             break;
+        bool can_steal = false;
+        if (STEAL && next >= P && K.csteal_follow) {
+            // A thief follows its victim's limit: the victim's walk comes BEFORE the stolen subtree in the reference's order, so
+            // whatever it has found by now the reference has found by the time it enters the subtree -- as long as the victim
+            // is still on the walk it was robbed on (its count of walks begun).
+            const int vl = vic & 63;
+            const float vt = __shfl(tb, vl);
+            const int vg = __shfl(gen, vl);
+            if (busy && thief && vg == (vic >> 8) && vt < tb) {
+                tb = vt;
+                sb = -1; // (what the thief had found lies behind it)
+            }
+        }
+        if (STEAL && next >= P) {
+            const unsigned long long thieves = __builtin_amdgcn_ballot_w64(!busy);
+            const bool is_victim0 = busy && active && sp > bot && nsteps >= K.csteal_min;
+            const unsigned long long victims = __builtin_amdgcn_ballot_w64(is_victim0);
+            if (thieves && victims) {
+                const int nt = __builtin_popcountll(thieves), nv = __builtin_popcountll(victims);
+                const int k = nt < nv ? nt : nv;
+                const int vrank = lane_prefix(victims), trank = lane_prefix(thieves);
+                const bool is_victim = is_victim0 && vrank < k;
+                if (is_victim)
+                    L.owner[vrank] = (unsigned char)lane;
+                wave_lds_order();
+                const bool steal = !busy && trank < k;
+                const int v = steal ? (int)L.owner[trank] : lane;
+                const int vb = __shfl(bot, v);
+                RayO npr;
+                npr.o = mk3(__shfl(pr.o.x, v), __shfl(pr.o.y, v), __shfl(pr.o.z, v));
+                npr.d = mk3(__shfl(pr.d.x, v), __shfl(pr.d.y, v), __shfl(pr.d.z, v));
+                npr.inv = mk3(__shfl(pr.inv.x, v), __shfl(pr.inv.y, v), __shfl(pr.inv.z, v));
+                const float ntb = __shfl(tb, v), nds = __shfl(dirScale, v);
+                const int nr = __shfl(r, v), noi = __shfl(oi | (xf ? 1 << 30 : 0), v), ng = __shfl(gen, v);
+                if (steal) {
+                    const uint2 e = L.stack[vb * 64 + v];
+                    const float tE = __uint_as_float(e.y);
+                    if (tE < ntb) { // (else the reference culls it as well: its limit is at most the victim's current one)
+                        cur = (int)e.x;
+                        tcur = tE;
+                        npr.sx = npr.inv.x < 0;
+                        npr.sy = npr.inv.y < 0;
+                        npr.sz = npr.inv.z < 0;
+                        pr = npr;
+                        tb = ntb;
+                        dirScale = nds;
+                        r = nr;
+                        oi = noi & ~(1 << 30);
+                        xf = (noi >> 30) & 1;
+                        rootref = -(1 << 30); // (a stolen subtree lies below the staged levels: its nodes come from memory)
+                        sp = bot = 0;
+                        nsteps = 0;
+                        sb = -1;
+                        ++gen;
+                        vic = v | (ng << 8);
+                        thief = true;
+                        busy = active = true;
+                        TS_EVENT(0);
+                    }
+                }
+                if (is_victim)
+                    ++bot;
+                wave_lds_order();
+            }
+            // (the node loop below yields every K.csteal steps only while a lane is idle AND a walk is, or soon will be, worth stealing from)
+            can_steal = thieves != 0ull && __builtin_amdgcn_ballot_w64(busy && active && nsteps + K.csteal >= K.csteal_min) != 0ull;
+        }
         // Inner nodes.  A lane needs ~2 node steps to its next leaf, the slowest of 64 needs ~12: the
         // descent stops as soon as K.leaf_min lanes wait at a leaf (wave-uniform loop, predicated step, so
         // the waiting lanes take part in the ballots); they are served below, pop, and rejoin it.
         const unsigned long long t_nd = TS_NOW();
+        int steps = 0;
         for (;;) {
             const bool innode = active && cur >= 0;
             if (!__builtin_amdgcn_ballot_w64(innode))
                 break;
-            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && cur < 0)) >= K.leaf_min)
+            // (with thieves at work few lanes idle through a descent, so it pays to gather more leaves per leaf phase)
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && cur < 0)) >= (STEAL ? K.csteal_leaf_min : K.leaf_min))
+                break;
+            if (STEAL && can_steal && ++steps > K.csteal) // idle lanes are waiting for stack entries to take
                 break;
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);
-                if (PT_TWO_LEVEL && !L.topnodes) {
+                if (STEAL)
+                    ++nsteps;
+                if (PT_TWO_LEVEL && !L.topnodes && !STEAL) {
                     if (descend2(K.nodes2, stk, sp, pr, tb, cur))
                         pop();
                     continue;
@@ -671,6 +787,8 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
                         ++sp;
                     }
                     cur = nearL ? Lr : Rr;
+                    if (STEAL)
+                        tcur = nearL ? tL : tR;
                 } else {
                     pop();
                 }
@@ -679,6 +797,9 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
         TS_ADDL(9, t_nd);
         const unsigned long long t_lf = TS_NOW();
         const bool atleaf = active && cur < 0;
+        if (STEAL && !__builtin_amdgcn_ballot_w64(atleaf)) {
+            // (a yield with no lane at a leaf: nothing to test)
+        } else
         if (K.leaf_pairs) {
             // Leaf phase as (lane, triangle) pairs.  Lane by lane it runs as long as the largest leaf (<= 17
             // tests) with the lanes that are not at a leaf idle: 21 % of the lanes busy on the showcase scene.
@@ -728,6 +849,10 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
                 if (key != ~0ull) {
                     tb = __uint_as_float((uint32_t)(key >> 32));
                     sb = first + (int)(uint32_t)key;
+                    if (STEAL && thief && !(tcur < tb)) { // a hit in front of its own leaf box: the reference may never have come here
+                        __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        TS_EVENT(1);
+                    }
                 }
                 pop();
             }
@@ -742,6 +867,7 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
                 p1 = tp[1];
                 p2 = tp[2];
             }
+            bool hit_here = false;
             for (int i = 0; i < lf.y; ++i) {
                 TS_WAVE(5);
                 TS_LANE(6);
@@ -751,11 +877,14 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
                 if (tri_test(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), pr, tb, t, u, v)) {
                     tb = t;
                     sb = lf.x + i;
+                    hit_here = true;
                 }
                 p0 = q0;
                 p1 = q1;
                 p2 = q2;
             }
+            if (STEAL && thief && hit_here && !(tcur < tb))
+                __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pop();
         }
         TS_ADDL(10, t_lf);
@@ -766,7 +895,15 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
                 const int ko = GEN ? (oi >> 2) : oi, kb = GEN ? (oi & (TLAS_SLOTS - 1)) * 64 + r : r;
                 const unsigned long long key =
                     ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)ko << 24) | (uint32_t)sb;
-                __hip_atomic_fetch_min(&L.best[kb], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long old = __hip_atomic_fetch_min(&L.best[kb], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (two walks of ONE pair at the same distance: the reference keeps the one it visits first, the minimum the
+                // lower slot)
+                if (STEAL && (old >> 24) == (key >> 24) && old != key) {
+                    __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    TS_EVENT(2);
+                    TS_DBG(old, key, (unsigned long long)r | ((unsigned long long)lane << 8) | ((unsigned long long)thief << 16) | ((unsigned long long)(unsigned)nsteps << 32),
+                           (unsigned long long)__float_as_uint(tcur) | ((unsigned long long)(unsigned)L.stat_bounce << 32));
+                }
             }
             busy = false;
         }
@@ -775,7 +912,7 @@ template <int GEN> PT_DEV void run_closest_queue(const KParams &K, const PairLds
     ts.v[0] = lane == 0 ? 1u : 0u;
     ts.v[1] = lane == 0 ? (unsigned)P : 0u;
 #endif
-    ts.flush(0, lane);
+    ts.flush(0, lane, L.stat_bounce);
 }
 
 // local-space distance of the winner in an instanced mesh, needed for localPoint (intersection.cuh:382,466)
@@ -792,11 +929,37 @@ PT_DEV float winner_t_local(const KParams &K, int mesh, int slot, f3 o, f3 d) {
 
 PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d) {
     const int P = build_pairs<false>(K, L, lane, alive, o, d, T_FAR);
+    const bool stealing = K.csteal > 0 && L.dirty; // (wave-uniform)
+    if (stealing && lane == 0)
+        L.dirty[0] = 0ull;
     wave_sync();
     const unsigned long long t_q = TS_NOW();
-    run_closest_queue<false>(K, L, lane, P, o, d);
+    if (stealing)
+        run_closest_queue<false, true>(K, L, lane, P, o, d);
+    else
+        run_closest_queue<false>(K, L, lane, P, o, d);
     TS_ADDL(8, t_q);
     wave_sync();
+    if (stealing) {
+        // rays a thief could not vouch for (run_closest_queue): traced again, every pair walked by one lane
+        const unsigned long long dm = L.dirty[0];
+        wave_sync();
+        if (dm) {
+#ifdef PT_TRAV_STATS
+            if (lane == 0)
+                atomicAdd(&g_trav_dbg[1025 + 3], (unsigned long long)__builtin_popcountll(dm));
+#endif
+            const unsigned long long keep = L.best[lane];
+            wave_sync();
+            const bool redo = alive && ((dm >> lane) & 1ull);
+            const int P2 = build_pairs<false>(K, L, lane, redo, o, d, T_FAR);
+            if (!redo) // (build_pairs resets every lane's minimum: the other rays' go back)
+                L.best[lane] = keep;
+            wave_sync();
+            run_closest_queue<false>(K, L, lane, P2, o, d);
+            wave_sync();
+        }
+    }
     const unsigned long long key = L.best[lane];
     wave_sync();
     Hit h;
@@ -1018,7 +1181,7 @@ template <int GEN> PT_DEV void run_any_queue(const KParams &K, const PairLds &L,
     ts.v[0] = lane == 0 ? 1u : 0u;
     ts.v[1] = lane == 0 ? (unsigned)P : 0u;
 #endif
-    ts.flush(8, lane);
+    ts.flush(8, lane, L.stat_bounce);
 }
 
 PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool alive, f3 o, f3 d, float tMax) {
@@ -1879,6 +2042,12 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
         if (PMODE == 1)
             TS_ADD(8, t_pa);
         const bool act = live && !fresh; // (has a ray: every live lane, unless K.sample_sync keeps it waiting)
+#ifdef PT_TRAV_STATS
+        {
+            const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+            PL.stat_bounce = am ? __builtin_amdgcn_readlane(sb >> 16, __builtin_ctzll(am)) : -1;
+        }
+#endif
         PT_MARK("B");
         phase_prio<PMODE, 1, 0>();
         const KParams &KB = kparams(kp0);

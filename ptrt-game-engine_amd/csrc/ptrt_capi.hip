@@ -188,6 +188,8 @@ struct ptrt_ctx {
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
+    int csteal_follow = 1, csteal_leaf_min = 32;
+    int csteal = 2, csteal_min = 0; // options: PMODE 2 closest-hit subtree stealing with verification (pt_render.hip.h run_closest_queue)
     int lds_pad = 0; // extra bytes of LDS per workgroup (A/B of the occupancy)
     // PMODE 1, simple materials: tiles per workgroup.  1 (default): five waves per SIMD.  2: two tiles share the LDS copies, six
     // waves per SIMD on 80 VGPRs -- measured on Cornell 1080p: 1.875 vs 1.877 ms, the 112 B per lane it spills eat what 24
@@ -607,6 +609,10 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.leaf_pairs = (c->leaf_pairs && (size_t)c->pair_max_leaf * 64 <= (size_t)pt::LEAF_PAIR_BYTES - 512) ? 1 : 0;
     K.leaf_min = c->leaf_min;
     K.steal = c->steal;
+    K.csteal = c->csteal;
+    K.csteal_min = c->csteal_min;
+    K.csteal_follow = c->csteal_follow;
+    K.csteal_leaf_min = c->csteal_leaf_min;
     K.cam = c->cam;
     K.sky_top = c->sky_top;
     K.sky_bottom = c->sky_bottom;
@@ -735,7 +741,7 @@ template <int GEOM, int PMODE> int launch_trace(ptrt_ctx *c, const pt::KParams &
 // shadow pairs get what is left of a 10-KB LDS budget (16 waves per CU), at least 64 (one mesh per pass), at most
 // another 64 * meshes (everything in one pass)
 int merged_pair_cap(const ptrt_ctx *c) {
-    const size_t rest = (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16;
+    const size_t rest = (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 24;
     const int lo = 64 * c->pair_meshes + 64, hi = 128 * c->pair_meshes;
     int cap = rest < 10240 ? (int)((10240 - rest) / 2) / 64 * 64 : 0;
     cap = cap < lo ? lo : cap;
@@ -744,15 +750,15 @@ int merged_pair_cap(const ptrt_ctx *c) {
 size_t pair_lds_bytes(const ptrt_ctx *c, int pmode) {
     if (pmode == 4)
         return (size_t)c->pair_meshes * 32 + 512 + 256 + (size_t)merged_pair_cap(c) * 2 +
-               (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16;
+               (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 24;
     if (pmode == 3) // no mesh table; pair list for one TLAS leaf per ray; TLAS stack + the rays' leaf starts
         return ((size_t)c->tlas_max_leaf * 64 + pt::TLAS_FILL_TARGET) * 2 + 512 * pt::TLAS_SLOTS +
                (size_t)c->stack_entries * 64 * sizeof(uint2) + (size_t)(c->tlas_depth < 1 ? 1 : c->tlas_depth) * 512 +
-               256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES + 16;
+               256 * pt::TLAS_SLOTS + pt::LEAF_PAIR_BYTES + 24;
     // staged heads (PMODE 1: and the mesh table), 16-bit pair entries, the rays' minima (whose second half holds the any-hit flags)
     const size_t common = (size_t)c->pair_meshes * (pmode == 1 ? 48 : 32) + (pmode == 1 ? pt::pm1_pair_bytes(c->pair_meshes) : (size_t)c->pair_meshes * 128) + 512;
     return pmode == 1 ? common + (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * pt::PAIR_PAD * 16 + 16
-                      : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 16; // (+ the ray totals)
+                      : common + (size_t)c->stack_entries * 64 * sizeof(uint2) + pt::LEAF_PAIR_BYTES + 24; // (+ the ray totals)
 }
 // 0 lock-step, 1 pairs over single-leaf BLASes, 2 pairs over general BLASes (single-leaf TLAS)
 int pair_mode(const ptrt_ctx *c, int geom, bool merged) {
@@ -2244,7 +2250,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     }
     if (c->merged < 0 && merged_possible && !capturing) {
         const unsigned long long key = ((((unsigned long long)c->n_geometry_uploads * 131 + (unsigned)spp) * 131 + (unsigned)max_depth) * 131 +
-                                        (unsigned)(c->steal * 64 + c->fetch_min)) * 131 + (unsigned)(c->leaf_min * 8 + c->leaf_pairs * 4 + c->lds_nodes * 2 + c->pair_trace);
+                                        (unsigned)(c->steal * 64 + c->fetch_min + c->csteal * 4096 + c->csteal_leaf_min * 65536)) * 131 + (unsigned)(c->leaf_min * 8 + c->leaf_pairs * 4 + c->lds_nodes * 2 + c->pair_trace);
         if (key != c->tune_key) {
             c->tune_key = key;
             c->tune_n = 0;
@@ -3055,6 +3061,21 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         if (value < 0 || value > 64)
             return fail(c, PTRT_E_INVALID, "steal must be 0..64");
         c->steal = (int)value;
+    } else if (n == "csteal") { // PMODE 2 closest hit: 0 = no subtree stealing; n = node steps between steal rounds (verified: same bits)
+        if (value < 0 || value > 64)
+            return fail(c, PTRT_E_INVALID, "csteal must be 0..64");
+        c->csteal = (int)value;
+    } else if (n == "csteal_follow")
+        c->csteal_follow = value ? 1 : 0;
+    else if (n == "csteal_leaf_min") {
+        if (value < 1 || value > 64)
+            return fail(c, PTRT_E_INVALID, "csteal_leaf_min must be 1..64");
+        c->csteal_leaf_min = (int)value;
+    }
+    else if (n == "csteal_min") {
+        if (value < 0 || value > 1024)
+            return fail(c, PTRT_E_INVALID, "csteal_min must be 0..1024");
+        c->csteal_min = (int)value;
     } else if (n == "lds_nodes") // PMODE 2 in 4-wave workgroups with the BLAS top levels staged in LDS (A/B, tests)
         c->lds_nodes = value < 0 ? 0 : (value > 2 ? 2 : (int)value); // (2: the larger workgroups without reading the staged nodes)
     else if (n == "merged") // PMODE 4 instead of 2: shadow rays ride with the next extension rays (A/B, tests)
@@ -3131,7 +3152,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::string n(name);
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
-        {"steal", c->steal}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
+        {"steal", c->steal}, {"csteal", c->csteal}, {"csteal_min", c->csteal_min}, {"csteal_follow", c->csteal_follow}, {"csteal_leaf_min", c->csteal_leaf_min}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
         {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"time_launches", c->time_launches}, {"tm_prio", c->tm_prio}, {"persist", c->persist}, {"refill", c->refill}, {"sample_sync", c->sample_sync}, {"sample_sync_eff", c->sample_sync_eff}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
@@ -3166,6 +3187,31 @@ int ptrt_debug_trav_stats(ptrt_ctx *c, unsigned long long *out32) {
     HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(pt::g_trav_stats), zero, sizeof(zero)));
     return PTRT_OK;
 }
+
+// ... and pt::g_trav_bounce (64 words: the sixteen traversal counters split by the rays' bounce 0, 1, 2, >= 3)
+int ptrt_debug_trav_bounce(ptrt_ctx *c, unsigned long long *out64) {
+    if (!ctx_live(c) || !out64)
+        return fail(c, PTRT_E_INVALID, "ptrt_debug_trav_bounce: bad argument");
+    if (int rc = set_device(c))
+        return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(pt::g_trav_bounce), 64 * sizeof(unsigned long long)));
+    unsigned long long zero[64] = {};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(pt::g_trav_bounce), zero, sizeof(zero)));
+    return PTRT_OK;
+}
+
+#ifdef PT_TRAV_STATS
+int ptrt_debug_trav_dbg(ptrt_ctx *c, unsigned long long *out1033) {
+    if (!ctx_live(c) || !out1033)
+        return fail(c, PTRT_E_INVALID, "ptrt_debug_trav_dbg: bad argument");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out1033, HIP_SYMBOL(pt::g_trav_dbg), 1033 * sizeof(unsigned long long)));
+    static unsigned long long zero[1033] = {};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(pt::g_trav_dbg), zero, sizeof(zero)));
+    return PTRT_OK;
+}
+#endif
 
 // test hook: exhaustive rcp_ieee check; out9[0] = mismatches, out9[1..8] = first offending inputs
 int ptrt_debug_rcp_check(ptrt_ctx *c, unsigned int *out9) {

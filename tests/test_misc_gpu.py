@@ -182,7 +182,7 @@ def test_full_size_traversal_variants_agree(P, scene):
              "fluid": lambda s: P.scenes.fluid(s, cells=256, t=0.3)}[scene]
     spp = 2 if scene == "fluid" else 4
     ref = _frames(P, build, {}, spp=spp)
-    plain = dict(fetch_min=0, leaf_pairs=0, steal=0, leaf_min=64, pair_split=0)
+    plain = dict(fetch_min=0, leaf_pairs=0, steal=0, csteal=0, leaf_min=64, pair_split=0)
     # ("many": 68 meshes behind a real TLAS -- PMODE 3 rounds against plain rounds and the lock-step general walk;
     #  the async / wavefront kernels take single-leaf TLASes only and fall back to the same default there)
     # merged=0: separate closest-hit and any-hit phases (PMODE 2) instead of one traversal per iteration (PMODE 4)
@@ -192,7 +192,8 @@ def test_full_size_traversal_variants_agree(P, scene):
     #   together (the default follows the depth limit and the mode; both are forced here for all four scenes)
     # refill=2: PMODE 1 as persistent waves whose lanes draw the next pixel of the launch (the default for overlapping frames)
     # tlas_rounds=1: shadow rays behind a real TLAS take one leaf per fill (the path of scenes with more than 1024 meshes)
-    for opts in (dict(merged=1), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1), dict(refill=2), dict(sample_sync=0), dict(sample_sync=1), dict(sample_sync=1, refill=2)):
+    # csteal: closest-hit subtree stealing with verification (PMODE 2's default) off / at its most eager / without the thieves following their victims' limits
+    for opts in (dict(merged=1), dict(merged=0, csteal=0), dict(merged=0, csteal=1, csteal_leaf_min=4), dict(merged=0, csteal=3, csteal_min=4, csteal_follow=0), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1), dict(refill=2), dict(sample_sync=0), dict(sample_sync=1), dict(sample_sync=1, refill=2)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):
             for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):
@@ -399,9 +400,10 @@ def test_launch_durations_of_overlapping_frames(P):
     a, b = s.launch_ms_history()
     assert len(a) == 0  # (option off)
     s.set_option("time_launches", 1)
-    for f in range(3, 9):
+    for f in range(3, 10):
         s.render_to_device(tgt[f & 1].data_ptr())
-        assert s.get_option("pipelined") == 1 and s.get_option("refilled") == 1
+        # (reading the history synchronises and counts as touching the context: the frame behind it waits for the stream)
+        assert s.get_option("pipelined") == (0 if f == 3 else 1) and s.get_option("refilled") == (0 if f == 3 else 1)
     a, b = s.launch_ms_history()
     assert len(a) == 12 and len(b) == 12 and (a > 0.05).all() and (a < 50).all() and (b > 0).all()
     k = s.kernel_ms_history(6)

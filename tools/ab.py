@@ -28,7 +28,7 @@ ap.add_argument("--depth", type=int, default=None)
 ap.add_argument("--denoise", action="store_true")
 ap.add_argument("--bloom", action="store_true")
 ap.add_argument("--one-target", action="store_true", help="render into ONE target: no frame overlaps its predecessor")
-a = ap.parse_args()
+a = ap.parse_intermixed_args()
 cfg = dict(CONFIGS.get(a.config, dict(scene=a.config, width=1920, height=1080, spp=4, depth=4)))
 if a.size:
     cfg["width"], cfg["height"] = (int(v) for v in a.size.split("x"))

@@ -33,6 +33,9 @@ s.stats()
 s.render_to_device(buf.data_ptr())
 torch.cuda.synchronize()
 assert P.lib.ptrt_debug_trav_stats(s.ctx, out) == 0
+outb = (C.c_ulonglong * 64)()
+P.lib.ptrt_debug_trav_bounce.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+assert P.lib.ptrt_debug_trav_bounce(s.ctx, outb) == 0
 st = s.stats()
 v = list(out)
 cy = dict(zip((8, 9, 10, 11, 12, 13, 14, 15), v[24:32]))  # cycle slots (CycleAcc)
@@ -55,6 +58,33 @@ for name, b in (("closest", 0), ("any-hit", 8)):
           f"({nl / max(1, pairs):.1f} nodes per pair)")
     print(f"   leaf phases/call {lp / calls:.1f}; triangle loop: {tw / calls:.1f} wave-iterations/call, lanes busy "
           f"{100.0 * tl / max(1, tw * 64):.1f} %  ({tl / max(1, pairs):.1f} triangles per pair)")
+vb = list(outb)
+if hasattr(P.lib, "ptrt_debug_trav_dbg"):
+    import struct
+    dbg = (C.c_ulonglong * 1033)()
+    P.lib.ptrt_debug_trav_dbg.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    P.lib.ptrt_debug_trav_dbg(s.ctx, dbg)
+    ev = list(dbg[1025:1033])
+    if any(ev):
+        print(f"closest-hit stealing: {ev[0]} subtrees stolen; {ev[3]} rays traced again without it ({ev[1]} marks for a thief's hit in front of "
+              f"its leaf box, {ev[2]} for equal distances from two walks of one pair)")
+    if os.environ.get("PT_DBG"):
+        f32 = lambda u: struct.unpack("f", struct.pack("I", u & 0xffffffff))[0]
+        print("debug records:", dbg[1024])
+        for i in range(min(40, dbg[1024])):
+            o, k, w, t = dbg[4 * i:4 * i + 4]
+            print(f"   old t={f32(o >> 32):.7g} order={(o >> 24) & 255} slot={o & 0xffffff}   key t={f32(k >> 32):.7g} order={(k >> 24) & 255} slot={k & 0xffffff}   "
+                  f"ray {w & 255} lane {(w >> 8) & 255} thief {(w >> 16) & 1} nsteps {w >> 32} tcur {f32(t):.7g} bounce {t >> 32}")
+if any(vb):  # the same counters by the rays' bounce (wave-uniform with the samples in step: sample_sync_eff)
+    print(f"by bounce (samples in step: {s.get_option('sample_sync_eff')}):")
+    for b in range(4):
+        for name, o in (("closest", 0), ("any-hit", 8)):
+            calls, pairs, nw, nl, lp, tw, tl, outer = vb[b * 16 + o:b * 16 + o + 8]
+            if not calls:
+                continue
+            print(f"   bounce {b if b < 3 else '3+'} {name:8s}: calls {calls:8d}  pairs/call {pairs / calls:5.1f}  node loop {nw / calls:5.1f} wave-it/call at "
+                  f"{100.0 * nl / max(1, nw * 64):4.1f} % busy ({nl / max(1, pairs):4.1f} nodes/pair)   triangle loop {tw / calls:5.1f} wave-it/call at "
+                  f"{100.0 * tl / max(1, tw * 64):4.1f} % busy   share of all node wave-iterations {100.0 * nw / max(1, v[o + 2]):4.1f} %")
 if cy[14]:  # instrumented build: where a wave's cycles go (s_memtime, summed over waves)
     tot = cy[14]
     pct = lambda k: 100.0 * cy[k] / tot

@@ -568,6 +568,19 @@ def main():
                 fluid_sources[src + "_ms"] = round(ms["dt"] / ms["steps"] * 1e3, 4)
         farm.fluid_source = args.fluid_source
         fluid_sources["gpu_commits, geometry_uploads"] = list(farm.scene.commitCounts())
+        # host time of one commit-path frame, split: the reference caller's rewrite (setTriangleSoup = what updatePTScene does
+        # to a `Triangles` mesh: 393,216 push_backs + the local box) and the mirror's commitObjectChanges() (topology check,
+        # vertex hand-over through pinned staging, refit launches); measured over a few more frames, GPU idle-waited per frame
+        farm.fluid_source = "commit"
+        c0 = farm.scene.commitHostMicros()
+        n_c = 12
+        for _ in range(n_c):
+            farm.step()
+        farm.fence()
+        c1 = farm.scene.commitHostMicros()
+        farm.fluid_source = args.fluid_source
+        fluid_sources["commit_host_us"] = {"caller": round((c1[0] - c0[0]) / n_c, 1), "mirror": round((c1[1] - c0[1]) / n_c, 1),
+                                           "mirror_face_compare": round((c1[2] - c0[2]) / n_c, 1)}
         fluid_sources["note"] = ("device: positions resident in HBM; host: + 4.7 MB H2D from pinned memory per step; commit: the "
                                  "reference's caller (updatePTScene's rewrite of mesh->vertices/faces on the host, dirty flags, "
                                  "commitObjectChanges()) under Scene::setDynamicGeometryPolicy(GpuRefit) -- its host work "

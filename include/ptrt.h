@@ -446,8 +446,13 @@ int ptrt_post_frame(ptrt_ctx *ctx, const float *accum, const float *normal, cons
  * them AFTER the farm); they must tile the frame exactly once, else PTRT_E_INVALID.
  *   ptrt_farm_render  = ptrt_render(ctx, frame, spp, depth, NULL, 0) on every context + ptrt_farm_gather
  *   ptrt_farm_gather  = gather of the images the contexts hold (for callers that render through the Scene mirror)
- *   ptrt_farm_transport: "device-copy" (all contexts on one device) or "rccl".  Errors: ptrt_last_error(NULL).
- * The "rccl" transport is UNVERIFIED ON HARDWARE (every test so far ran on a one-GPU box).  A presentation-ring slot as the
+ *   ptrt_farm_transport: "device-copy" (all contexts on one device), "rccl", or "peer-copy": hipMemcpyPeerAsync of a remote
+ *                     context's image onto the presenting device, on the farm's stream behind the context's render -- no RCCL
+ *                     involved (SURVEY 8(e) names it as the alternative).  "peer-copy" is what a farm uses when librccl cannot be
+ *                     loaded or ncclCommInitAll fails, with PTRT_FARM_TRANSPORT=peer in the environment, or after
+ *                     ptrt_farm_set_option(farm, "transport", 1) (0 = back to RCCL, refused if its communicators never came
+ *                     up).  Errors: ptrt_last_error(NULL).
+ * The "rccl" AND "peer-copy" transports are UNVERIFIED ON HARDWARE (every test so far ran on a one-GPU box).  A presentation-ring slot as the
  * device target (rtgl::map_pbo_device_ptr) is recognised: its download is ordered behind the gather's copies. */
 typedef struct ptrt_farm ptrt_farm;
 int ptrt_farm_create(ptrt_ctx *const *contexts, int n_contexts, ptrt_farm **out);
@@ -466,7 +471,7 @@ int ptrt_farm_gather(ptrt_farm *farm, void *out_rgb8, int out_is_device);
  *                        straight into it (ptrt_render(..., frame, PTRT_OUT_DEVICE_FRAME), as ptrt_farm_render makes them do)
  *                        is not copied by the gather, only waited for
  *   ptrt_farm_set_option "parallel" 0|1 (default 1), "spin_us" (a worker polls that long for the next frame before it
- *                        sleeps; default 2000) */
+ *                        sleeps; default 2000), "transport" 0|1 (see ptrt_farm_transport) */
 int ptrt_farm_parallel(ptrt_farm *farm, void (*fn)(int part, void *user), void *user);
 double ptrt_farm_host_us(const ptrt_farm *farm);
 void *ptrt_farm_device_frame(ptrt_farm *farm, void *out_rgb8, int out_is_device);
@@ -537,6 +542,10 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *                         stream the launch runs on: ptrt_launch_ms_history (default 0: six more driver calls per frame)
  *   tm_prio 0..3          lane refill's tonemap pass: |1 on a stream of the highest priority (hipStreamCreateWithPriority) forked from
  *                         and joined to its launch's stream, |2 its waves at s_setprio 3 (A/B: DESIGN.md 3.12)
+ *   atrous_exp 0|1        denoiser: 1 = the a-trous luminance weight exp(-dl^2 / 2 sigma^2) through the hardware exponential (v_exp_f32), as
+ *                         the reference's `__expf` (denoiser.cuh:731); 0 (default) = the deterministic exponential the oracle defines,
+ *                         bit-exact.  Mode 1 is held to a stated tolerance against the oracle (tests/test_denoiser.py: per-pixel
+ *                         relative L2 of the denoised HDR image <= 1e-5 (measured 3.9e-7), RGB8 within 1 LSB)
  *   denoiser_active, motion_vectors, use_graphs 0|1 */
 int ptrt_set_option(ptrt_ctx *ctx, const char *name, long long value);
 /* Reads an option back, and -- read-only -- what the last ptrt_render launched, so that a measurement can name the kernel it

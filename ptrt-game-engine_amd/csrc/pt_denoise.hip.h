@@ -177,19 +177,37 @@ PT_DEV float blend1(float a, float b, float c, float d, const Taps &t) {
 // entries, ids and histories, the nearest texel -- issued up front and unconditionally, since every address is known before any
 // test: 112-114 us against 103-116 as written, at 94 instead of 72 VGPRs.  Its 80 % of wave-cycles in s_waitcnt are not the
 // dependent chains of the source.)
+// (Round 4: the 3x3 neighbourhood -- colour, {normal, depth}, object id of nine pixels, 27 gathers per thread through the
+// texture addresser -- comes out of an LDS copy of the workgroup's 66 x 6 footprint, staged with coalesced loads as the a-trous
+// passes do; the four history taps sit at motion-dependent addresses and stay gathers.)
+constexpr int TP_SPAN = 64 + 2, TP_ENT = TP_SPAN * (4 + 2);
 __global__ __launch_bounds__(256) void temporal_kernel(float4 *__restrict__ oh1, float4 *__restrict__ oh2,
                                                        const float4 *__restrict__ cur4, const float4 *__restrict__ ph1,
                                                        const float4 *__restrict__ ph2, const float *__restrict__ motion,
                                                        const float4 *__restrict__ g4, const float4 *__restrict__ pg4,
                                                        const int *__restrict__ object_id, const int *__restrict__ pobj,
                                                        DenoiseSettings S, int first_frame, int W, int H) {
-    PT_PIXEL_XY
+    __shared__ float4 s_c[TP_ENT], s_g[TP_ENT];
+    __shared__ int s_o[TP_ENT];
     const bool use_obj = S.use_object_ids != 0;
-    const f3 cur_c = xyz(cur4[idx]);
-    const float4 g = g4[idx];
+    {
+        const int bx = blockIdx.x * 64 - 1, by = blockIdx.y * 4 - 1;
+        for (int e = threadIdx.x; e < TP_ENT; e += 256) { // entry (ex, ey) = pixel (clamp(bx + ex), clamp(by + ey)): the taps' own clamping
+            const int ey = e / TP_SPAN, ex = e - ey * TP_SPAN;
+            const int pi = clampi(by + ey, 0, H - 1) * W + clampi(bx + ex, 0, W - 1);
+            s_c[e] = cur4[pi];
+            s_g[e] = g4[pi];
+            s_o[e] = use_obj ? object_id[pi] : -1;
+        }
+    }
+    __syncthreads();
+    PT_PIXEL_XY
+    const int ce = ((threadIdx.x >> 6) + 1) * TP_SPAN + (threadIdx.x & 63) + 1;
+    const f3 cur_c = xyz(s_c[ce]);
+    const float4 g = s_g[ce];
     const float d = g.w;
     const f3 n = xyz(g);
-    const int obj_id = use_obj ? object_id[idx] : -1;
+    const int obj_id = s_o[ce];
     if (is_sky(d, n, S.sky_depth_threshold)) {
         oh1[idx] = mk4(cur_c, 1.0f);
         oh2[idx] = mk4(cur_c * cur_c, 0.0f);
@@ -197,13 +215,15 @@ __global__ __launch_bounds__(256) void temporal_kernel(float4 *__restrict__ oh1,
     }
     f3 nmean = mk3(0.0f), nm2 = mk3(0.0f);
     int ncount = 0;
+#pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
-            const int ni = clampi(y + dy, 0, H - 1) * W + clampi(x + dx, 0, W - 1);
-            const float4 ng = g4[ni];
-            const int no = use_obj ? object_id[ni] : -1;
+            const int ne = ce + dy * TP_SPAN + dx;
+            const float4 ng = s_g[ne];
+            const int no = s_o[ne];
             if (!edge_disc(d, ng.w, n, xyz(ng), obj_id, no, S.edge_depth_threshold, S.edge_normal_threshold, use_obj)) {
-                const f3 nc = xyz(cur4[ni]);
+                const f3 nc = xyz(s_c[ne]);
                 nmean = nmean + nc;
                 nm2 = nm2 + nc * nc;
                 ncount++;
@@ -361,8 +381,11 @@ __global__ __launch_bounds__(256) void variance_kernel(float4 *__restrict__ out_
 constexpr int AT_W = 64, AT_ROWS = 4;
 constexpr int AT_OUTSIDE = (int)0x80000000; // object-id slot of a footprint entry that lies outside the image
 PT_DEV int atrous_span(int step) { return AT_W + 4 * step; }
-inline size_t atrous_lds_bytes(int step) { return (size_t)(AT_W + 4 * step) * (AT_ROWS + 4) * 36; }
-template <bool LAST>
+inline size_t atrous_lds_bytes(int step) { return (size_t)(AT_W + 4 * step) * (AT_ROWS + 4) * 40; }
+// FAST (option "atrous_exp" 1): the luminance weight through the hardware exponential, v_exp_f32(x log2 e) -- what the reference
+// itself computes there (`__expf`, denoiser.cuh:731) -- instead of the 27-instruction deterministic one the oracle defines;
+// a stated-tolerance mode (tests/test_denoiser.py), the bit-exact mode is the default.
+template <bool LAST, bool FAST = false>
 __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4, const float4 *__restrict__ in_c4,
                                                      const float4 *__restrict__ g4, const int *__restrict__ object_id,
                                                      int step, float sigma_lum, float sky, float edt, float ent, int use_obj_i,
@@ -373,6 +396,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
     const int span = atrous_span(step), entries = span * (AT_ROWS + 4);
     float4 *s_c = at_lds, *s_g = at_lds + entries;
     int *s_o = reinterpret_cast<int *>(at_lds + 2 * entries);
+    float *s_l = reinterpret_cast<float *>(s_o + entries); // luminance of the entry's colour: computed once here, not by each of the 25 taps that read it
     const int x0 = blockIdx.x * AT_W, ry = blockIdx.y % step, tyd = blockIdx.y / step;
     {   // threads 0..127 stage footprint row 2k, threads 128..255 row 2k+1 (span <= 128 for step <= 16)
         const int ex = threadIdx.x & 127;
@@ -386,7 +410,9 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                 if (px >= 0 && px < W && yd >= 0 && py < H) {
                     const int pi = py * W + px;
                     const float4 gv = g4[pi];
-                    s_c[e] = in_c4[pi];
+                    const float4 cv = in_c4[pi];
+                    s_c[e] = cv;
+                    s_l[e] = luminance(xyz(cv));
                     s_g[e] = gv;
                     // (a sky pixel is skipped by every tap that reaches it, whatever its other tests say -- the reference's
                     // `continue`s have no side effects --, so it is marked like a pixel outside the image, once, here,
@@ -410,7 +436,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
     const f3 cc = xyz(c4), cn = xyz(g);
     const float cd = g.w, cvar = c4.w;
     const int cobj = uo ? s_o[ce] : -1;
-    const float clum = luminance(cc);
+    const float clum = s_l[ce];
     f3 res = cc;
     float res_var = cvar;
     if (!is_sky(cd, cn, sky)) {
@@ -437,6 +463,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                 const int nobj = s_o[ne];
                 const float4 ng = s_g[ne];
                 const float4 nc4 = s_c[ne];
+                const float nlum = s_l[ne];
                 bool ok = nobj != AT_OUTSIDE; // nx < 0 || nx >= W || ny < 0 || ny >= H
                 ok = ok && !(uo && cobj != nobj && cobj >= 0 && nobj >= 0);
                 const float max_d = max_(cd, ng.w);
@@ -451,8 +478,8 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                 ok = ok && !(dot(cn, nn) < ent); // (a sky neighbour carries AT_OUTSIDE: staging)
                 if (ok) {
                     const f3 nc = xyz(nc4);
-                    const float ld = __builtin_fabsf(clum - luminance(nc));
-                    const float wl = det_exp(-ld * ld * inv_sl2);
+                    const float ld = __builtin_fabsf(clum - nlum);
+                    const float wl = FAST ? __builtin_amdgcn_exp2f((-ld * ld * inv_sl2) * 1.44269504f) : det_exp(-ld * ld * inv_sl2);
                     // atrous_kernel[k] = (a*b)/256 with a,b in {1,4,6}: products and the /256 are exact in fp32
                     const float weight = (KW[dy + 2] * KW[dx + 2] / 256.0f) * wl;
                     sum = sum + nc * weight;

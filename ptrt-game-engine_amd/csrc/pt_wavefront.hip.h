@@ -265,15 +265,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // ---------------------------------------------------------------------------------------------
 // shade: one thread per path.  The body is phases [A], [C], [E] of path_trace_kernel (pt_render.hip.h),
 // i.e. scene_kernels.cuh:147-193 and tracePath (path_logic.cuh:782-899), cut at the two traces.
-template <bool FULL> __global__ __launch_bounds__(256) void wf_shade_kernel(const KParams K, const WfParams W) {
-    if (W.iter > 0 && W.live[W.iter - 1] == 0u)
-        return;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool first = W.iter == 0;
-    const size_t N = (size_t)W.n_items;
+struct WfCounts {
     uint32_t n_ext = 0, n_shadow = 0, n_paths = 0, n_zero = 0;
     bool alive_after = false;
+};
+template <bool FULL> PT_DEV void wf_shade_path(const KParams &K, const WfParams &W, const int q, WfCounts &cn) {
+    const bool first = W.iter == 0;
+    const size_t N = (size_t)W.n_items;
+    uint32_t &n_ext = cn.n_ext, &n_shadow = cn.n_shadow, &n_paths = cn.n_paths, &n_zero = cn.n_zero;
+    bool &alive_after = cn.alive_after;
     if (q < W.n_items) {
         const int tile = q >> 6, l = q & 63;
         const int tx = tile % K.tiles_x, ty = tile / K.tiles_x;
@@ -573,7 +573,78 @@ template <bool FULL> __global__ __launch_bounds__(256) void wf_shade_kernel(cons
             }
         }
     }
-    if (__builtin_amdgcn_ballot_w64(alive_after) && lane == 0)
+}
+
+// Active-path sorting (option "wf_sort"; north_star: "wavefront ballot/prefix-sum for ray compaction and active-path sorting";
+// path_logic.cuh:490-780 is where a wave of unsorted paths diverges: transmissive / clear-coated / iridescent / sheen / plain
+// branches of material_scatter, evaluateBSDF and material_pdf, six importance_sample_ggx sites).  The paths are one frame-wide pool
+// in tile order; a workgroup takes WF_SORT_G x 256 consecutive ones, bins them by class in LDS -- counting sort: LDS histogram,
+// a wave's prefix sum over the classes, LDS cursors -- and its waves then shade runs of ONE class: finished and idle paths
+// first (those waves leave at once: compaction), then regenerations, misses, and the hits by {mesh = material, the ray's
+// specular flag, bounce >= 2 (roulette)}.  Which thread shades a path changes nothing in the path: same bits.
+constexpr int WF_CLASSES = 3 + 64 * 4; // (WF_SORT_G, the kernel's third template argument: 256-path groups a workgroup sorts together, 0 = no sorting)
+PT_DEV int wf_class(const WfParams &W, int q) {
+    if (q >= W.n_items)
+        return 0;
+    const uint32_t st = W.st[q];
+    if (st & WF_DONE)
+        return 0;
+    if ((st & WF_ENDED) || !(st & WF_EXT))
+        return 1; // resolves its light sample and starts the next sample
+    const int mesh = __float_as_int(W.hit[q].z);
+    if (mesh < 0)
+        return 2; // sky
+    return 3 + (mesh & 63) * 4 + ((st & WF_SPEC) ? 1 : 0) + ((((st >> 8) & 0xffu) >= 2u) ? 2 : 0);
+}
+
+template <bool FULL, int WF_SORT_G = 0> __global__ __launch_bounds__(256) void wf_shade_kernel(const KParams K, const WfParams W) {
+    constexpr bool SORT = WF_SORT_G > 0;
+    if (W.iter > 0 && W.live[W.iter - 1] == 0u)
+        return;
+    const int lane = threadIdx.x & 63;
+    WfCounts cn;
+    if (SORT) {
+        __shared__ int hist[WF_CLASSES + 1], order[256 * (SORT ? WF_SORT_G : 1)];
+        const int seg0 = blockIdx.x * 256 * WF_SORT_G;
+        for (int i = threadIdx.x; i <= WF_CLASSES; i += 256)
+            hist[i] = 0;
+        __syncthreads();
+        int cls[SORT ? WF_SORT_G : 1];
+#pragma unroll
+        for (int g = 0; g < WF_SORT_G; ++g) {
+            cls[g] = wf_class(W, seg0 + g * 256 + (int)threadIdx.x);
+            atomicAdd(&hist[cls[g]], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) { // exclusive prefix sum over the classes, 64 at a time (one wave)
+            int carry = 0;
+            for (int c0 = 0; c0 < WF_CLASSES; c0 += 64) {
+                const int c = c0 + lane;
+                const int v = c < WF_CLASSES ? hist[c] : 0;
+                int inc = v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(inc, off);
+                    if (lane >= off)
+                        inc += t;
+                }
+                if (c < WF_CLASSES)
+                    hist[c] = carry + inc - v;
+                carry += __shfl(inc, 63);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < WF_SORT_G; ++g)
+            order[atomicAdd(&hist[cls[g]], 1)] = seg0 + g * 256 + (int)threadIdx.x;
+        __syncthreads();
+#pragma unroll 1
+        for (int g = 0; g < WF_SORT_G; ++g)
+            wf_shade_path<FULL>(K, W, order[g * 256 + threadIdx.x], cn);
+    } else {
+        wf_shade_path<FULL>(K, W, blockIdx.x * 256 + threadIdx.x, cn);
+    }
+    const uint32_t n_ext = cn.n_ext, n_shadow = cn.n_shadow, n_paths = cn.n_paths, n_zero = cn.n_zero;
+    if (__builtin_amdgcn_ballot_w64(cn.alive_after) && lane == 0)
         W.live[W.iter] = 1u; // same value from every writer
     if (K.counters) {
         uint32_t a = n_ext, b = n_shadow, c = n_paths, z = n_zero;

@@ -152,6 +152,7 @@ struct ptrt_ctx {
 
     // wavefront stages (pt_wavefront.hip.h): per-path state, planar, tile-ordered
     int wavefront = 0; // option: 1 = render scenes with a single-leaf TLAS through the trace/shade stages
+    int wf_sort = 0;   // option: the shade stage bins its paths by class first (active-path sorting, pt_wavefront.hip.h)
     uint32_t *wf_st = nullptr, *wf_occ = nullptr, *wf_live = nullptr;
     float *wf_planes = nullptr; // 25 planes: ray 6, thr 3, acc 3, avg 3, pend 3, shadow ray 7
     float4 *wf_hit = nullptr;
@@ -188,6 +189,7 @@ struct ptrt_ctx {
 
     // options
     int count_rays = 0, force_geom = -1, force_full = 0, pair_trace = 1, fetch_min = 16, leaf_pairs = 1, steal = 1, leaf_min = 8;
+    int atrous_exp = 0; // option: 1 = the a-trous luminance weight through v_exp_f32 (the reference's __expf) instead of det_exp: tolerance mode
     int csteal_follow = 1, csteal_leaf_min = 32;
     int csteal = 2, csteal_min = 0; // options: PMODE 2 closest-hit subtree stealing with verification (pt_render.hip.h run_closest_queue)
     int lds_pad = 0; // extra bytes of LDS per workgroup (A/B of the occupancy)
@@ -841,7 +843,13 @@ int run_wavefront(ptrt_ctx *c, const pt::KParams &K, bool full, int spp, int max
         W.iter = it;
         if (it > 0)
             hipLaunchKernelGGL(pt::wf_trace_kernel, dim3(trace_blocks), dim3(256), lds, c->stream, K, W);
-        if (full)
+        if (c->wf_sort && it > 0) { // (the first shade only regenerates: one class)
+            const int G = c->wf_sort;
+            const int sb = (int)((items + 256 * (size_t)G - 1) / (256 * (size_t)G));
+            auto kern = full ? (G == 1 ? pt::wf_shade_kernel<true, 1> : G == 2 ? pt::wf_shade_kernel<true, 2> : pt::wf_shade_kernel<true, 4>)
+                             : (G == 1 ? pt::wf_shade_kernel<false, 1> : G == 2 ? pt::wf_shade_kernel<false, 2> : pt::wf_shade_kernel<false, 4>);
+            hipLaunchKernelGGL(kern, dim3(sb), dim3(256), 0, c->stream, K, W);
+        } else if (full)
             hipLaunchKernelGGL(pt::wf_shade_kernel<true>, dim3(shade_blocks), dim3(256), 0, c->stream, K, W);
         else
             hipLaunchKernelGGL(pt::wf_shade_kernel<false>, dim3(shade_blocks), dim3(256), 0, c->stream, K, W);
@@ -1057,14 +1065,12 @@ int run_denoiser(ptrt_ctx *c, const pt::KParams &K, unsigned char *rgb8) {
         const int s = steps[i];
         const dim3 agrid((W + pt::AT_W - 1) / pt::AT_W, (((H + s - 1) / s + pt::AT_ROWS - 1) / pt::AT_ROWS) * s);
         const size_t alds = pt::atrous_lds_bytes(s);
-        if (i == iters - 1)
-            hipLaunchKernelGGL(pt::atrous_kernel<true>, agrid, block, alds, c->stream, out, in, c->dn_g4[next], K.object_id,
-                               steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
-                               S.edge_normal_threshold, S.use_object_ids, W, H, c->dn_out, rgb8);
-        else
-            hipLaunchKernelGGL(pt::atrous_kernel<false>, agrid, block, alds, c->stream, out, in, c->dn_g4[next], K.object_id,
-                               steps[i], S.sigma_luminance, S.sky_depth_threshold, S.edge_depth_threshold,
-                               S.edge_normal_threshold, S.use_object_ids, W, H, (float *)nullptr, (unsigned char *)nullptr);
+        const bool last = i == iters - 1;
+        auto kern = last ? (c->atrous_exp ? pt::atrous_kernel<true, true> : pt::atrous_kernel<true, false>)
+                         : (c->atrous_exp ? pt::atrous_kernel<false, true> : pt::atrous_kernel<false, false>);
+        hipLaunchKernelGGL(kern, agrid, block, alds, c->stream, out, in, c->dn_g4[next], K.object_id, steps[i], S.sigma_luminance,
+                           S.sky_depth_threshold, S.edge_depth_threshold, S.edge_normal_threshold, S.use_object_ids, W, H,
+                           last ? c->dn_out : (float *)nullptr, last ? rgb8 : (unsigned char *)nullptr);
     }
     if (iters == 0)
         hipLaunchKernelGGL(pt::c4_to_output_kernel, grid, block, 0, c->stream, c->dn_c4[0], W, H, c->dn_out, rgb8);
@@ -3065,7 +3071,9 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         if (value < 0 || value > 64)
             return fail(c, PTRT_E_INVALID, "csteal must be 0..64");
         c->csteal = (int)value;
-    } else if (n == "csteal_follow")
+    } else if (n == "atrous_exp")
+        c->atrous_exp = value ? 1 : 0;
+    else if (n == "csteal_follow")
         c->csteal_follow = value ? 1 : 0;
     else if (n == "csteal_leaf_min") {
         if (value < 1 || value > 64)
@@ -3130,6 +3138,8 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->leaf_min = c->as_leaf_min = (int)value;
     } else if (n == "wavefront") // 1: trace/shade stages over the whole frame's rays instead of the megakernel
         c->wavefront = value ? 1 : 0;
+    else if (n == "wf_sort") // wavefront stages: the shade stage sorts its paths by class (material, bounce) in LDS first, 1 / 2 / 4 groups of 256 together
+        c->wf_sort = value <= 0 ? 0 : (value >= 4 ? 4 : (value >= 2 ? 2 : 1));
     else if (n == "fetch_min") { // PMODE 2: refill threshold in idle lanes; 0 = static batches of 64 pairs (A/B, tests)
         if (value < 0 || value > 64)
             return fail(c, PTRT_E_INVALID, "fetch_min must be 0..64");
@@ -3152,9 +3162,9 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::string n(name);
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
-        {"steal", c->steal}, {"csteal", c->csteal}, {"csteal_min", c->csteal_min}, {"csteal_follow", c->csteal_follow}, {"csteal_leaf_min", c->csteal_leaf_min}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
+        {"steal", c->steal}, {"csteal", c->csteal}, {"csteal_min", c->csteal_min}, {"csteal_follow", c->csteal_follow}, {"atrous_exp", c->atrous_exp}, {"csteal_leaf_min", c->csteal_leaf_min}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
         {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"time_launches", c->time_launches}, {"tm_prio", c->tm_prio}, {"persist", c->persist}, {"refill", c->refill}, {"sample_sync", c->sample_sync}, {"sample_sync_eff", c->sample_sync_eff}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
-        {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
+        {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"wf_sort", c->wf_sort}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch
         {"render_mode", c->last_mode},   // 0 megakernel, 1 wavefront stages, 2 asynchronous lanes

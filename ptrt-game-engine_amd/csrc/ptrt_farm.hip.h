@@ -14,6 +14,11 @@
 // No host synchronisation inside a frame; the next render of a context waits (on its stream) until its image has
 // been taken.  RCCL is loaded on first use (dlopen), so the library has no link-time dependency on it and a
 // single-GPU box never touches it.
+// A second transport needs no RCCL at all (SURVEY 8(e) names it): "peer-copy" -- hipMemcpyPeerAsync of a remote context's
+// image into the presenting device's staging buffer on the farm's stream, behind the context's `rendered` event, and the
+// context's next render behind a `taken` event of the presenting device.  Chosen when librccl cannot be loaded or
+// ncclCommInitAll fails, by PTRT_FARM_TRANSPORT=peer in the environment, or by ptrt_farm_set_option("transport", 1);
+// ptrt_farm_transport() says which one a farm uses.  PEER PATH UNVERIFIED ON HARDWARE as well (one-GPU boxes only).
 // RCCL PATH UNVERIFIED ON HARDWARE: every test so far ran on a one-GPU box, where the transport is "device-copy"; dlopen,
 // ncclCommInitAll, the grouped send/receive on mixed streams (also two contexts on one remote device) and CommDestroy have
 // never executed.  tests/test_farm_gpu.py takes the devices it finds, so its first run on a multi-GPU node is that test.
@@ -93,6 +98,8 @@ struct ptrt_farm {
     bool primed = false;
     int parallel = 1, spin_us = 2000;
     std::string transport = "device-copy";
+    bool remote = false, peer = false;       // contexts on other devices exist / they are fetched with hipMemcpyPeerAsync
+    std::string rccl_error;                  // why RCCL is not available to this farm (empty: it is, or was never needed)
 };
 
 namespace {
@@ -285,20 +292,45 @@ int ptrt_farm_create(ptrt_ctx *const *bands, int n_bands, ptrt_farm **out) {
         f->comm_rank[(size_t)i] = (int)k;
     }
     if (f->comm_dev.size() > 1) {
-        if (!rccl().ok)
-            return bail(PTRT_E_HIP, "contexts on several devices need RCCL (librccl.so), which could not be loaded");
-        f->comms.assign(f->comm_dev.size(), nullptr);
-        const ncclResult_t r = rccl().CommInitAll(f->comms.data(), (int)f->comm_dev.size(), f->comm_dev.data());
-        if (r != ncclSuccess)
-            return bail(PTRT_E_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r));
-        f->transport = "rccl";
+        f->remote = true;
+        const char *want = getenv("PTRT_FARM_TRANSPORT");
+        const bool want_peer = want && std::string(want) == "peer";
+        if (!want_peer) {
+            if (!rccl().ok) {
+                f->rccl_error = "librccl.so could not be loaded";
+            } else {
+                f->comms.assign(f->comm_dev.size(), nullptr);
+                const ncclResult_t r = rccl().CommInitAll(f->comms.data(), (int)f->comm_dev.size(), f->comm_dev.data());
+                if (r != ncclSuccess) {
+                    f->rccl_error = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
+                    f->comms.clear();
+                }
+            }
+        }
+        // without RCCL (not wanted, not loadable, or its communicators did not come up) the images are fetched by peer copies
+        f->peer = want_peer || f->comms.empty();
+        f->transport = f->peer ? "peer-copy" : "rccl";
+        if (f->peer) {
+            (void)hipSetDevice(f->device);
+            for (size_t k = 1; k < f->comm_dev.size(); ++k) { // direct xGMI reads where the platform allows (else the runtime stages)
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, f->device, f->comm_dev[k]) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(f->comm_dev[k], 0);
+                (void)hipGetLastError();
+            }
+        }
     }
     for (int i = 0; i < n_bands; ++i) {
         e = hipSetDevice(bands[i]->device);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&f->rendered[(size_t)i], hipEventDisableTiming);
+        // (`taken` is recorded on the farm's stream: an event of the PRESENTING device, also for a context elsewhere)
+        if (e == hipSuccess)
+            e = hipSetDevice(f->device);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&f->taken[(size_t)i], hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipSetDevice(bands[i]->device);
         if (e == hipSuccess && f->comm_rank[(size_t)i] >= 0) {
             e = hipSetDevice(f->device);
             if (e == hipSuccess)
@@ -346,8 +378,23 @@ int ptrt_farm_gather(ptrt_farm *f, void *out_rgb8, int out_is_device) {
         return fail(nullptr, PTRT_E_HIP, "ptrt_farm_gather: no device frame");
     HIP_TRY(nullptr, hipSetDevice(f->device));
     const size_t n = f->band.size();
-    // remote images: sends on the contexts' streams (behind their render), receives on the farm's stream, one group
-    if (!f->comms.empty()) {
+    // remote images, peer-copy transport: fetched by the presenting device behind the context's render
+    if (f->remote && f->peer) {
+        for (size_t i = 0; i < n; ++i) {
+            ptrt_ctx *c = f->band[i];
+            if (f->comm_rank[i] < 0)
+                continue;
+            HIP_TRY(nullptr, hipSetDevice(c->device));
+            HIP_TRY(nullptr, hipEventRecord(f->rendered[i], c->stream));
+            HIP_TRY(nullptr, hipSetDevice(f->device));
+            HIP_TRY(nullptr, hipStreamWaitEvent(f->stream, f->rendered[i], 0));
+            HIP_TRY(nullptr, hipMemcpyPeerAsync(f->staging[i], f->device, c->d_rgb8, c->device, c->npix * 3, f->stream));
+            HIP_TRY(nullptr, hipEventRecord(f->taken[i], f->stream)); // the context's next render may overwrite its image behind this
+            HIP_TRY(nullptr, hipStreamWaitEvent(c->stream, f->taken[i], 0));
+        }
+    }
+    // remote images, RCCL transport: sends on the contexts' streams (behind their render), receives on the farm's stream, one group
+    if (f->remote && !f->peer) {
         ncclResult_t r = rccl().GroupStart();
         for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
             ptrt_ctx *c = f->band[i];
@@ -469,6 +516,15 @@ int ptrt_farm_set_option(ptrt_farm *f, const char *name, long long value) {
         f->spin_us = (int)value;
         for (auto &w : f->workers)
             w->spin_us.store((int)value);
+    } else if (n == "transport") { // 0: RCCL send / receive for contexts on other devices (if its communicators came up); 1: peer copies
+        if (value != 0 && value != 1)
+            return fail(nullptr, PTRT_E_INVALID, "transport must be 0 (rccl) or 1 (peer-copy)");
+        if (value == 0 && f->remote && f->comms.empty())
+            return fail(nullptr, PTRT_E_HIP, "ptrt_farm_set_option: RCCL is not available to this farm (%s)",
+                        f->rccl_error.empty() ? "peer-copy was chosen at creation" : f->rccl_error.c_str());
+        f->peer = value == 1;
+        if (f->remote)
+            f->transport = f->peer ? "peer-copy" : "rccl";
     } else
         return fail(nullptr, PTRT_E_INVALID, "ptrt_farm_set_option: unknown option '%s'", name);
     return PTRT_OK;

@@ -172,7 +172,22 @@ int hs_mesh_set_vertices(void *s, int mesh, const float *xyz, int n_verts) {
 }
 // What updatePTScene does to a `Triangles` mesh whose triangleVerts changed (PTRTtransfer.cuh:2249-2270): vertices and faces
 // rewritten as an unshared-vertex soup, both dirty flags set, the local box recomputed -- the caller commits afterwards.
+static double g_soup_us = 0.0; // host time of hs_mesh_set_triangle_soup so far: the CALLER's share of a commit (bench.py --via-commit)
+int hs_commit_host_us(void *s, double *caller_us, double *mirror_us, double *compare_us) {
+    const Scene *sc = static_cast<Scene *>(s);
+    if (caller_us)
+        *caller_us = g_soup_us;
+    if (mirror_us)
+        *mirror_us = sc->commitHostMicros();
+    if (compare_us)
+        *compare_us = sc->commitCompareMicros();
+    return 0;
+}
 int hs_mesh_set_triangle_soup(void *s, int mesh, const float *verts9, int n_tris) {
+    struct Timer {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Timer() { g_soup_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+    } timer;
     Mesh *m = static_cast<Scene *>(s)->getMesh((size_t)mesh);
     if (!m || !verts9 || n_tris < 1) {
         g_err = "hs_mesh_set_triangle_soup: bad argument";

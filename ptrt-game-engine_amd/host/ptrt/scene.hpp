@@ -12,6 +12,7 @@
 #include "hdr.hpp"
 #include "mesh.hpp"
 
+#include <chrono>
 #include <cstdint>
 #include <iostream>
 #include <memory>
@@ -541,6 +542,11 @@ class Scene {
     }
     DynamicGeometryPolicy getDynamicGeometryPolicy() const { return dynPolicy; }
     // commits that took the GPU path / that re-uploaded the geometry (tests, bench)
+    // host time (microseconds, accumulated) the mirror itself spends in a commit -- updateAccelerationStructures(): the
+    // dynamic-geometry policy's topology check, the vertex hand-over, the refit / rebuild launches, the host structures --
+    // and of that the part spent comparing face lists; for measurements (bench.py --via-commit), not part of the reference's API
+    double commitHostMicros() const { return commitMicros; }
+    double commitCompareMicros() const { return compareMicros; }
     size_t gpuDynamicCommitCount() const { return gpuDynamicCommits; }
     size_t geometryUploadCount() const { return geometryUploads; }
     // Dynamic geometry with unchanged topology (the fluid-sim caller, PTRTtransfer.cuh:2249-2270):
@@ -956,8 +962,9 @@ class Scene {
     DynamicGeometryPolicy dynPolicy = DynamicGeometryPolicy::HostRebuild;
     std::vector<std::vector<Tri>> uploadedFaces;
     std::vector<size_t> uploadedVerts;
-    std::vector<unsigned char> hostTreeStale;
+    std::vector<unsigned char> hostTreeStale, uploadedSoup;
     size_t gpuDynamicCommits = 0, geometryUploads = 0;
+    double commitMicros = 0.0, compareMicros = 0.0;
 
     void needBackend() const {
         if (!ctx)
@@ -1129,8 +1136,12 @@ class Scene {
             if (!m->bvhDirty && !m->vertsDirty)
                 continue;
             const std::vector<Tri> &uf = uploadedFaces[i];
-            if (m->bvhNodes.empty() || m->vertices.size() != uploadedVerts[i] || m->faces.size() != uf.size() ||
-                std::memcmp(m->faces.data(), uf.data(), uf.size() * sizeof(Tri)) != 0)
+            if (m->bvhNodes.empty() || m->vertices.size() != uploadedVerts[i] || m->faces.size() != uf.size())
+                return false;
+            const auto c0 = std::chrono::steady_clock::now();
+            const bool same = sameFaces(*m, i);
+            compareMicros += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
+            if (!same)
                 return false;
             moved.push_back(i);
         }
@@ -1157,6 +1168,22 @@ class Scene {
         ++gpuDynamicCommits;
         return true;
     }
+    // Is the face list of mesh i what the device holds?  A `Triangles` mesh as updatePTScene rewrites it (PTRTtransfer.cuh:2249-2270)
+    // is an unshared-vertex soup: face k = {3k, 3k+1, 3k+2}.  If the uploaded list was that soup (noted at upload), the new
+    // list is checked against the PATTERN -- one pass over 12 bytes per face, no second array to stream -- else word by word
+    // against the copy kept from the upload.
+    bool sameFaces(const Mesh &m, size_t i) const {
+        const std::vector<Tri> &uf = uploadedFaces[i];
+        if (i < uploadedSoup.size() && uploadedSoup[i]) {
+            const Tri *f = m.faces.data();
+            const int n = (int)m.faces.size();
+            int bad = 0;
+            for (int k = 0; k < n; ++k) // (branch-free: the compiler vectorises it)
+                bad |= (f[k].v0 ^ (3 * k)) | (f[k].v1 ^ (3 * k + 1)) | (f[k].v2 ^ (3 * k + 2));
+            return bad == 0;
+        }
+        return std::memcmp(m.faces.data(), uf.data(), uf.size() * sizeof(Tri)) == 0;
+    }
     // host copies of the trees the GPU refitted (boxes) or rebuilt (prim order, then boxes); true if any changed
     bool syncHostTrees() {
         bool any = false;
@@ -1179,6 +1206,11 @@ class Scene {
     void updateAccelerationStructures() {
         if (meshes.empty())
             return;
+        struct Timer {
+            double &acc;
+            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            ~Timer() { acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+        } timer{commitMicros};
         if (!ctx) { // host-only scene: the host half of a commit (trees, TLAS, material arrays); there is nothing to upload to
             prepareHostStructures();
             return;
@@ -1194,13 +1226,20 @@ class Scene {
             // what the device now holds, for the dynamic-geometry policy
             uploadedFaces.resize(meshes.size());
             uploadedVerts.resize(meshes.size());
+            uploadedSoup.assign(meshes.size(), 0);
             hostTreeStale.assign(meshes.size(), 0);
             for (size_t i = 0; i < meshes.size(); ++i) {
                 uploadedVerts[i] = meshes[i]->vertices.size();
-                if (dynPolicy != DynamicGeometryPolicy::HostRebuild)
+                if (dynPolicy != DynamicGeometryPolicy::HostRebuild) {
                     uploadedFaces[i] = meshes[i]->faces;
-                else
+                    const std::vector<Tri> &f = uploadedFaces[i];
+                    bool soup = f.size() * 3 == meshes[i]->vertices.size();
+                    for (size_t k = 0; soup && k < f.size(); ++k)
+                        soup = f[k].v0 == (int)(3 * k) && f[k].v1 == (int)(3 * k + 1) && f[k].v2 == (int)(3 * k + 2);
+                    uploadedSoup[i] = soup ? 1 : 0;
+                } else {
                     uploadedFaces[i].clear(); // (the default policy pays nothing for the copies)
+                }
             }
         } else if (instancesDirty) {
             check(ptrt_update_instances(ctx, flat.meshes, flat.mesh_count, flat.tlas_nodes, flat.tlas_node_count,

@@ -195,6 +195,7 @@ _sig("hs_mesh_set_vertices", C.c_int, _vp, C.c_int, _fp, C.c_int)
 _sig("hs_mesh_set_triangle_soup", C.c_int, _vp, C.c_int, _fp, C.c_int)
 _sig("hs_set_dynamic_geometry_policy", C.c_int, _vp, C.c_int)
 _sig("hs_commit_counts", C.c_int, _vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
+_sig("hs_commit_host_us", C.c_int, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("hs_mesh_counts", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("hs_add_point_light", None, _vp, _fp, _fp, C.c_float, C.c_float, C.c_float)
 _sig("hs_add_directional_light", None, _vp, _fp, _fp, C.c_float)
@@ -414,6 +415,13 @@ class Scene:
         a, b = C.c_longlong(), C.c_longlong()
         lib.hs_commit_counts(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def commitHostMicros(self):
+        """(caller, mirror, compare): accumulated host microseconds of setTriangleSoup (what updatePTScene does to a `Triangles`
+        mesh), of the commits themselves (updateAccelerationStructures) and, within those, of the face-list comparison."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        lib.hs_commit_host_us(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     def meshCounts(self, mesh):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

@@ -134,6 +134,14 @@ def test_c_abi_farm_host_time_and_options(P):
     assert P.lib.ptrt_farm_host_us(farm) > 0.0
     assert P.lib.ptrt_farm_set_option(farm, b"parallel", 0) == 0 and P.lib.ptrt_farm_set_option(farm, b"spin_us", 50) == 0
     assert P.lib.ptrt_farm_set_option(farm, b"nonsense", 1) == -1
+    # transport of contexts on OTHER devices: 0 RCCL send / receive, 1 hipMemcpyPeerAsync by the presenting device (no RCCL at
+    # all).  Every context of this farm sits on one device, so the choice is accepted, changes nothing in the frame, and the
+    # farm keeps reporting "device-copy"; a value that names no transport is refused.  (Both remote transports are UNVERIFIED
+    # ON HARDWARE: no run on more than one GPU exists.)
+    P.lib.ptrt_farm_transport.restype = C.c_char_p
+    P.lib.ptrt_farm_transport.argtypes = [C.c_void_p]
+    assert P.lib.ptrt_farm_set_option(farm, b"transport", 1) == 0 and P.lib.ptrt_farm_transport(farm) == b"device-copy"
+    assert P.lib.ptrt_farm_set_option(farm, b"transport", 2) == -1 and b"transport" in P.lib.ptrt_last_error(None)
     for s in parts:
         s.reset_rng(P.DEFAULT_SEED)
     assert P.lib.ptrt_farm_render(farm, 0, 1, 4, out[1].ctypes.data_as(C.c_void_p), 0) == 0

@@ -21,17 +21,21 @@ def test_cornell_single_leaf_blases(P, O, blue_noise, size, spp, depth, frames):
     s = P.Scene(size[0], size[1])
     P.scenes.cornell(s)
     s.set_option("wavefront", 1)
+    s.set_option("wf_sort", 1 if spp == 2 else 0)  # (a ragged frame through the sorting shade stage as well)
     gpu, cpu = render_both(P, O, s, blue_noise, spp, depth, frames)
     assert mode(P, s) == 1
     assert_frames_equal(gpu, cpu)
     s.close()
 
 
-@pytest.mark.parametrize("fetch_min", [1, 16, 64])
-def test_showcase_all_material_branches(P, O, blue_noise, fetch_min):
+@pytest.mark.parametrize("fetch_min,wf_sort", [(1, 0), (16, 0), (64, 0), (16, 1)])
+def test_showcase_all_material_branches(P, O, blue_noise, fetch_min, wf_sort):
+    """(wf_sort = 1: the shade stage bins its paths by {finished, regenerating, miss, mesh x specular flag x roulette} in LDS
+    before shading them -- active-path sorting; which thread shades a path changes nothing in it)"""
     s = P.Scene(96, 64)
     P.scenes.showcase(s, segments=12)
     s.set_option("wavefront", 1)
+    s.set_option("wf_sort", wf_sort)
     s.set_option("fetch_min", fetch_min)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 5, 2)
     assert mode(P, s) == 1
@@ -79,7 +83,7 @@ def test_band_context(P, O, blue_noise):
 def test_equals_megakernel_at_scale(P, blue_noise):
     """640x360 showcase, 4 spp, 4 bounces, 2 frames: every buffer equals the megakernel's."""
     out = []
-    for wf in (0, 1):
+    for wf in (0, 1, 2):  # megakernel, wavefront stages, wavefront stages with active-path sorting
         s = P.Scene(640, 360)
         P.scenes.showcase(s)
         s.setPerfSamplesPerPixel(4)
@@ -89,16 +93,18 @@ def test_equals_megakernel_at_scale(P, blue_noise):
         s.initBlueNoise()
         s.uploadToGPU()
         s.set_option("count_rays", 1)
-        s.set_option("wavefront", wf)
+        s.set_option("wavefront", 1 if wf else 0)
+        s.set_option("wf_sort", 1 if wf == 2 else 0)
         fr = []
         for _ in range(2):
             rgb = s.render_to_host()
             fr.append(dict(accum=s.read(P.BUF_ACCUM), normal=s.read(P.BUF_NORMAL), depth=s.read(P.BUF_DEPTH),
                            object_id=s.read(P.BUF_OBJECT_ID), rgb8=rgb, rng=s.read(P.BUF_RNG), stats=s.stats()))
-        assert mode(P, s) == wf
+        assert mode(P, s) == (1 if wf else 0)
         out.append(fr)
         s.close()
-    for a, b in zip(*out):
-        for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):
-            assert np.array_equal(bits(a[k]), bits(b[k])), k
-        assert a["stats"] == b["stats"]
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):
+                assert np.array_equal(bits(a[k]), bits(b[k])), k
+            assert a["stats"] == b["stats"]

@@ -304,6 +304,7 @@ class Farm:
             over = self._max_over_ranks(time.perf_counter() - t_all) > budget_s
             if done or over:
                 break
+        self.ramp_ms = [round(h * 1e3, 4) for h in hist]
         return n
 
     def measure(self, steps, warmup, ramp=True, time_launches=True):
@@ -318,6 +319,7 @@ class Farm:
         while self.tuning_frames < 16 and not self.scene.get_option("merged_decided"):
             self.step()
             self.tuning_frames += 1
+        self.ramp_ms = []
         self.ramp_frames = self.ramp() if ramp else 0
         # events around every launch of the timed frames, on the stream the launch runs on (ptrt_launch_ms_history): overlapping
         # frames are two launches each on auxiliary streams, and what the roofline is priced on is THOSE launches
@@ -369,7 +371,7 @@ class Farm:
             self.dist.all_reduce(tsum, op=self.dist.ReduceOp.SUM)
             dt, rays, kernel_ms, rays_ref = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tsum[3])
         return dict(dt=dt, rays=rays, rays_ref=rays_ref, kernel_ms=kernel_ms, steps=steps, tuning_frames=self.tuning_frames,
-                    ramp_frames=self.ramp_frames, launch=launch, kernel_alone_ms=kernel_alone_ms,
+                    ramp_frames=self.ramp_frames, ramp_ms=self.ramp_ms, launch=launch, kernel_alone_ms=kernel_alone_ms,
                     overlapped=overlapped, refilled=refilled, sample_sync=int(self.scene.get_option("sample_sync_eff")),
                     pmode=self.scene.get_option("pmode"), merged_eff=self.scene.get_option("merged_eff"),
                     render_mode=self.scene.get_option("render_mode"))
@@ -664,7 +666,7 @@ def main():
                                + (" +gpu-rebuild" if args.rebuild else ""), "name": args.config, "scene": cfg["scene"],
                    "width": W, "height": H, "spp": spp_used, "max_depth": depth_used,
                    "parallelism": (f"tile{world}-{layout}" + ("+post-on-rank0" if post_on_rank0 else "")) if world > 1 else "single",
-                   "kernel": kernel_name(m), "tuning_frames": m["tuning_frames"], "ramp_frames": m["ramp_frames"],
+                   "kernel": kernel_name(m), "tuning_frames": m["tuning_frames"], "ramp_frames": m["ramp_frames"], "ramp_block_ms": m["ramp_ms"],
                    "library": P.library_info(),
                    "frames_overlap": m["overlapped"], "samples_in_step": bool(m.get("sample_sync")),
                    "pmode": int(m["pmode"]), "merged_eff": int(m["merged_eff"]), "lane_refill": bool(m["refilled"])},

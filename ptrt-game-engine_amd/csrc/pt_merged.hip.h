@@ -78,13 +78,17 @@ PT_DEV int build_pairs_merged(const KParams &K, const PairLds &L, int lane, bool
 
 // Drains the mixed pair queue [0, P).  Afterwards L.best[r] = min over ray r's closest-hit pairs of
 // {t bits, order << 24 | slot} and L.occ[r] != 0 iff one of its any-hit pairs found a hit.
+// CSTEAL: closest-hit pairs may be stolen from as well -- verified subtree stealing, see run_closest_queue (pt_render.hip.h): a
+// thief's hit in front of its own leaf box and equal distances from two walks of one pair mark the ray in L.dirty[0], and
+// trace_merged traces marked rays again with CSTEAL off.
+template <bool CSTEAL>
 PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P, f3 eo, f3 ed, f3 so, f3 sd, float stmax,
                              CycleAcc &cyc) {
     LdsStack stk{L.stack + lane};
     int next = 0;
-    bool busy = false, active = false, isany = false, xf = false;
-    int cur = 0, sp = 0, bot = 0, r = 0, oi = 0, sb = -1;
-    float dirScale = 1.0f, tb = T_FAR; // closest: the pair's running limit; any: the ray's fixed limit
+    bool busy = false, active = false, isany = false, xf = false, thief = false;
+    int cur = 0, sp = 0, bot = 0, r = 0, oi = 0, sb = -1, gen = 0, vic = 0;
+    float dirScale = 1.0f, tb = T_FAR, tcur = 0.0f; // closest: the pair's running limit; any: the ray's fixed limit
     RayO pr = make_ray(mk3(0.0f), mk3(0.0f, 0.0f, 1.0f));
     TravStats ts;
     // next subtree of this lane's stack that can still matter (E1); an any-hit pair whose ray is already known
@@ -100,6 +104,7 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
             stk.pop(sp, ref, tE);
             if (tE < tb) {
                 cur = ref;
+                tcur = tE;
                 active = true;
                 break;
             }
@@ -147,6 +152,8 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 cur = mt.x;
                 sp = bot = 0;
                 sb = -1;
+                thief = false;
+                ++gen;
                 busy = active = true;
             }
             next += n_idle;
@@ -156,9 +163,19 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
         // ---- subtree stealing among the any-hit pairs (see run_any_queue): once the queue is empty an idle lane
         // takes the BOTTOM stack entry of a busy any-hit lane together with a copy of its ray
         bool can_steal = false;
-        if (K.steal && next >= P) {
+        const bool csteal = CSTEAL && K.csteal > 0; // (wave-uniform)
+        if (csteal && next >= P && K.csteal_follow) { // a closest-hit thief follows its victim's limit while that walk lasts
+            const int vl = vic & 63;
+            const float vt = __shfl(tb, vl);
+            const int vg = __shfl(gen, vl);
+            if (busy && thief && !isany && vg == (vic >> 8) && vt < tb) {
+                tb = vt;
+                sb = -1;
+            }
+        }
+        if ((K.steal || csteal) && next >= P) {
             const unsigned long long thieves = __builtin_amdgcn_ballot_w64(!busy);
-            const bool is_victim = busy && isany && active && sp > bot;
+            const bool is_victim = busy && (isany ? K.steal != 0 : csteal) && active && sp > bot;
             const unsigned long long victims = __builtin_amdgcn_ballot_w64(is_victim);
             if (thieves && victims) {
                 const int nt = __builtin_popcountll(thieves), nv = __builtin_popcountll(victims);
@@ -174,28 +191,40 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 npr.o = mk3(__shfl(pr.o.x, v), __shfl(pr.o.y, v), __shfl(pr.o.z, v));
                 npr.d = mk3(__shfl(pr.d.x, v), __shfl(pr.d.y, v), __shfl(pr.d.z, v));
                 npr.inv = mk3(__shfl(pr.inv.x, v), __shfl(pr.inv.y, v), __shfl(pr.inv.z, v));
-                const float ntb = __shfl(tb, v);
-                const int nr = __shfl(r, v);
+                const float ntb = __shfl(tb, v), nds = __shfl(dirScale, v);
+                const int nr = __shfl(r, v), ng = __shfl(gen, v);
+                const int noi = __shfl(oi | (xf ? 1 << 30 : 0) | (isany ? 1 << 29 : 0), v);
                 if (steal) {
                     const uint2 e = L.stack[vb * 64 + v];
-                    cur = (int)e.x;
-                    npr.sx = npr.inv.x < 0;
-                    npr.sy = npr.inv.y < 0;
-                    npr.sz = npr.inv.z < 0;
-                    pr = npr;
-                    tb = ntb;
-                    r = nr;
-                    isany = true;
-                    sp = bot = 0;
-                    sb = -1;
-                    busy = active = true;
+                    const float tE = __uint_as_float(e.y);
+                    if (tE < ntb) { // (a closest-hit entry the reference culls as well; any-hit entries carry 0)
+                        cur = (int)e.x;
+                        tcur = tE;
+                        npr.sx = npr.inv.x < 0;
+                        npr.sy = npr.inv.y < 0;
+                        npr.sz = npr.inv.z < 0;
+                        pr = npr;
+                        tb = ntb;
+                        dirScale = nds;
+                        r = nr;
+                        oi = noi & ~(3 << 29);
+                        xf = (noi >> 30) & 1;
+                        isany = (noi >> 29) & 1;
+                        sp = bot = 0;
+                        sb = -1;
+                        ++gen;
+                        vic = v | (ng << 8);
+                        thief = true;
+                        busy = active = true;
+                    }
                 }
                 if (is_victim && vrank < k)
                     ++bot;
                 wave_lds_order();
             }
-            can_steal = thieves != 0ull && __builtin_amdgcn_ballot_w64(busy && isany) != 0ull;
+            can_steal = thieves != 0ull && __builtin_amdgcn_ballot_w64(busy && active && (isany ? K.steal != 0 : csteal)) != 0ull;
         }
+        const int yield_n = csteal ? K.csteal : K.steal, leaf_min = csteal ? K.csteal_leaf_min : K.leaf_min;
         // ---- inner nodes: wave-uniform loop with a predicated step; ends once K.leaf_min lanes wait at a leaf, or
         // after K.steal steps while idle lanes wait for stack entries to take
         TS_ADD(11, t_it);
@@ -205,14 +234,14 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
             const bool innode = active && cur >= 0;
             if (!__builtin_amdgcn_ballot_w64(innode))
                 break;
-            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && cur < 0)) >= K.leaf_min)
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && cur < 0)) >= leaf_min)
                 break;
-            if (can_steal && ++steps > K.steal)
+            if (can_steal && ++steps > yield_n)
                 break;
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);
-                if (PT_TWO_LEVEL) { // (any-hit pairs walk like closest-hit ones here, with a fixed limit)
+                if (PT_TWO_LEVEL && !CSTEAL) { // (any-hit pairs walk like closest-hit ones here, with a fixed limit)
                     if (descend2(K.nodes2, stk, sp, pr, tb, cur))
                         pop();
                     continue;
@@ -230,6 +259,8 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                         ++sp;
                     }
                     cur = nearL ? Lr : Rr;
+                    if (CSTEAL)
+                        tcur = nearL ? tL : tR;
                 } else {
                     pop();
                 }
@@ -286,6 +317,8 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                     if (key != ~0ull) {
                         tb = __uint_as_float((uint32_t)(key >> 32));
                         sb = first + (int)(uint32_t)key;
+                        if (CSTEAL && thief && !(tcur < tb)) // a hit in front of its own leaf box: the reference may never have come here
+                            __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     pop();
                 }
@@ -297,7 +330,9 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 const float tw = xf ? tb / dirScale : tb;
                 const unsigned long long key =
                     ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)oi << 24) | (uint32_t)sb;
-                __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long old = __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (CSTEAL && (old >> 24) == (key >> 24) && old != key) // two walks of one pair at the same distance
+                    __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             busy = false;
         }
@@ -322,16 +357,37 @@ PT_DEV void trace_merged(const KParams &K, const PairLds &L, int lane, bool ext,
     const int n_mesh = K.pair_meshes;
     int s_next = 0;
     bool first = true;
+    const bool stealing = K.csteal > 0 && L.dirty; // (wave-uniform)
+    if (stealing && lane == 0)
+        L.dirty[0] = 0ull;
     for (;;) {
         const int s_from = s_next;
         const int P = build_pairs_merged(K, L, lane, first, ext_in, we, sh_in, ws, stmax, s_from, s_next);
         wave_sync();
-        run_merged_queue(K, L, lane, P, eo, ed, so, sd, stmax, cyc);
+        if (stealing)
+            run_merged_queue<true>(K, L, lane, P, eo, ed, so, sd, stmax, cyc);
+        else
+            run_merged_queue<false>(K, L, lane, P, eo, ed, so, sd, stmax, cyc);
         wave_sync();
         first = false;
         // (the list is sized so that this is one pass unless nearly every ray touches nearly every mesh)
         if (s_next >= n_mesh || !__builtin_amdgcn_ballot_w64(sh_in && L.occ[lane] == 0u))
             break;
+    }
+    if (stealing) { // extension rays a thief could not vouch for: traced again, every pair walked by one lane
+        const unsigned long long dm = L.dirty[0];
+        wave_sync();
+        if (dm) {
+            TS_EVENT(3);
+            const bool redo = ext_in && ((dm >> lane) & 1ull);
+            if (redo)
+                L.best[lane] = ~0ull;
+            int dummy = 0;
+            const int P2 = build_pairs_merged(K, L, lane, true, redo, we, false, ws, stmax, n_mesh, dummy);
+            wave_sync();
+            run_merged_queue<false>(K, L, lane, P2, eo, ed, so, sd, stmax, cyc);
+            wave_sync();
+        }
     }
     const unsigned long long key = L.best[lane];
     occluded = sh && (L.occ[lane] != 0u);

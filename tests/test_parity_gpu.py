@@ -395,15 +395,20 @@ def test_pair_queue_refill_thresholds(P, O, blue_noise, fetch_min, leaf_pairs, l
 
 @pytest.mark.parametrize("csteal,csteal_min,leaf_pairs,leaf_min,fetch_min", [(1, 0, 1, 8, 16), (2, 0, 0, 64, 0), (4, 8, 1, 8, 16),
                                                                              (1, 2, 1, 1, 1), (8, 0, 1, 24, 64)])
-def test_closest_hit_stealing_is_exact(P, O, blue_noise, csteal, csteal_min, leaf_pairs, leaf_min, fetch_min):
+@pytest.mark.parametrize("merged", [0, 1])
+def test_closest_hit_stealing_is_exact(P, O, blue_noise, csteal, csteal_min, leaf_pairs, leaf_min, fetch_min, merged):
     """PMODE 2, option csteal: idle lanes take the bottom entry of a busy closest-hit walk's stack, with a copy of its ray and
     limit, and merge what they find; a ray for which a thief accepted a hit in front of its leaf box, or two walks of one pair
     reported the same distance, is traced again without stealing (run_closest_queue).  The oracle's bits at
     every threshold (csteal_min = 0: every walk is stolen from at once), with both leaf phases -- showcase materials, an
     instanced mesh with tiny leaves, and the water grid, whose triangle edges lie ON leaf-box faces (the case in which a
     looser limit finds a hit the sequential walk culls)."""
+    if merged and not leaf_pairs:
+        pytest.skip("the merged traversal always uses the compacted leaf phase")
+
     def opts(s):
-        s.set_option("merged", 0)
+        s.set_option("merged", merged)  # (1: PMODE 4, closest-hit and shadow pairs in one queue, both kinds stolen from)
+        s.set_option("steal", 1)
         s.set_option("csteal", csteal)
         s.set_option("csteal_min", csteal_min)
         s.set_option("leaf_pairs", leaf_pairs)
@@ -415,7 +420,7 @@ def test_closest_hit_stealing_is_exact(P, O, blue_noise, csteal, csteal_min, lea
     P.scenes.showcase(s, segments=12)
     opts(s)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 5, 2)
-    assert s.get_option("pmode") == 2
+    assert s.get_option("pmode") == (4 if merged else 2)
     assert_frames_equal(gpu, cpu)
     s.close()
     s = P.Scene(72, 64)
@@ -433,7 +438,7 @@ def test_closest_hit_stealing_is_exact(P, O, blue_noise, csteal, csteal_min, lea
     P.scenes.fluid(s, cells=64, t=0.3)
     opts(s)
     gpu, cpu = render_both(P, O, s, blue_noise, 2, 4, 2)
-    assert s.get_option("pmode") == 2
+    assert s.get_option("pmode") == (4 if merged else 2)
     assert_frames_equal(gpu, cpu)
     s.close()
 

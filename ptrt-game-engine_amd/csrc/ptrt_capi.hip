@@ -2291,8 +2291,11 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     }
     const int pmode = pair_mode(c, geom, c->merged_eff != 0);
     c->last_pmode = pmode;
-    if (c->merged < 0 && pmode == 4)
-        K.steal = 0; // (the merged loop is at its best without shadow-ray subtree stealing: 3.98 vs 4.17 ms on the showcase frame)
+    // (round 2: the merged loop was at its best WITHOUT shadow-ray subtree stealing, 3.98 vs 4.17 ms on the showcase frame -- its
+    // yields served ten shadow pairs at the price of sixty closest-hit walks; with the closest-hit walks stolen from as well the
+    // yields pay for both kinds: 3.19 ms with, 3.49 without)
+    if (c->merged < 0 && pmode == 4 && c->csteal == 0)
+        K.steal = 0;
     const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
     // (the heads only change with the mesh records: a frame since whose predecessor no entry point touched the device keeps them)
     if (pmode == 3 && (c->touched || !c->heads_fresh)) { // (outside the timed kernel: a 136-thread copy)

@@ -43,3 +43,17 @@ def test_two_rank_rehearsal(layout):
     d = _line(subprocess.check_output(cmd, cwd=ROOT, env=env, stderr=subprocess.DEVNULL, timeout=300))
     assert KEYS <= set(d) and d["n_gpus"] == 2 and "rehearsal" in d and d["config"]["parallelism"] == f"tile2-{layout}"
     assert d["rays_per_frame"] > 320 * 200 * 4  # both ranks' rays
+
+
+def test_plain_invocation_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE (how the driver starts it): the process -- before it
+    imports anything that touches a device -- starts the two ranks itself (python -m torch.distributed.run as a child, a free
+    rendezvous port on 127.0.0.1), passes rank 0's line through and exits with the child's code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PTRT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+    assert r.returncode == 0
+    d = _line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and "rehearsal" in d and d["config"]["parallelism"] == "tile2-strips"
+    assert d["config"]["ramp_frames"] >= 10

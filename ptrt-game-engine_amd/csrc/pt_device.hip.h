@@ -1039,4 +1039,64 @@ PT_DEV void tonemap_pixel(f3 hdr, unsigned char &r, unsigned char &g, unsigned c
     b = (unsigned char)rgb.z;
 }
 
+
+// Per-function probe for tests (ptrt_debug_shade; SURVEY 8(c) golden item 7: scalar known answers for a11-a13).
+//   op 0: item = {material id, N(3), V(3), L(3), front_face}  -> {evaluateBSDF(3), material_pdf}
+//   op 1: item = {material id, N(3), ray_dir(3), front_face, generator state (6 words)} ->
+//                {scattered_dir(3), attenuation(3), flags (1 ok | 2 specular), generator state after (6 words)}
+template <bool FULL> __global__ void shade_probe_kernel(const float4 *__restrict__ materials, int op, const float *__restrict__ in,
+                                                        int n, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    if (op == 0) {
+        const float *p = in + (size_t)i * 11;
+        const Material mat = load_material(materials, (int)p[0]);
+        Surface h;
+        h.point = mk3(0.0f);
+        h.normal = mk3(p[1], p[2], p[3]);
+        h.t = 1.0f;
+        h.front_face = p[10] != 0.0f;
+        const f3 V = mk3(p[4], p[5], p[6]), L = mk3(p[7], p[8], p[9]);
+        const f3 f = evaluateBSDF<FULL>(h, mat, L, V);
+        float *o = out + (size_t)i * 4;
+        o[0] = f.x;
+        o[1] = f.y;
+        o[2] = f.z;
+        o[3] = material_pdf<FULL>(h, mat, V, L);
+    } else {
+        const float *p = in + (size_t)i * 14;
+        const Material mat = load_material(materials, (int)p[0]);
+        Surface h;
+        h.point = mk3(0.0f);
+        h.normal = mk3(p[1], p[2], p[3]);
+        h.t = 1.0f;
+        h.front_face = p[7] != 0.0f;
+        Rng rng;
+        rng.d = __float_as_uint(p[8]);
+        rng.v0 = __float_as_uint(p[9]);
+        rng.v1 = __float_as_uint(p[10]);
+        rng.v2 = __float_as_uint(p[11]);
+        rng.v3 = __float_as_uint(p[12]);
+        rng.v4 = __float_as_uint(p[13]);
+        f3 dir = mk3(0.0f), att = mk3(0.0f);
+        bool spec = false;
+        const bool ok = material_scatter<FULL>(h, mat, mk3(p[4], p[5], p[6]), rng, dir, att, spec);
+        float *o = out + (size_t)i * 13;
+        o[0] = dir.x;
+        o[1] = dir.y;
+        o[2] = dir.z;
+        o[3] = att.x;
+        o[4] = att.y;
+        o[5] = att.z;
+        o[6] = (float)((ok ? 1 : 0) | (spec ? 2 : 0));
+        o[7] = __uint_as_float(rng.d);
+        o[8] = __uint_as_float(rng.v0);
+        o[9] = __uint_as_float(rng.v1);
+        o[10] = __uint_as_float(rng.v2);
+        o[11] = __uint_as_float(rng.v3);
+        o[12] = __uint_as_float(rng.v4);
+    }
+}
+
 } // namespace pt

@@ -3296,6 +3296,31 @@ int ptrt_debug_detmath(ptrt_ctx *c, int op, const float *x, const float *y, int 
     return PTRT_OK;
 }
 
+// test hook: the shading functions one by one on the device (pt::shade_probe_kernel) over the context's uploaded materials;
+// op 0: n items of 11 floats -> 4 floats each; op 1: n items of 14 -> 13 (see the kernel).  full = 0: the simple-material variant
+int ptrt_debug_shade(ptrt_ctx *c, int op, int full, const float *in, int n, float *out) {
+    if (!ctx_live(c) || !in || !out || n <= 0 || (op != 0 && op != 1))
+        return fail(c, PTRT_E_INVALID, "ptrt_debug_shade: bad argument");
+    if (!c->have_materials)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_debug_shade: materials not uploaded");
+    if (int rc = set_device(c))
+        return rc;
+    const size_t ni = (size_t)n * (op == 0 ? 11 : 14) * 4, no = (size_t)n * (op == 0 ? 4 : 13) * 4;
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&din, ni));
+    HIP_TRY(c, hipMalloc((void **)&dout, no));
+    HIP_TRY(c, hipMemcpy(din, in, ni, hipMemcpyHostToDevice));
+    if (full)
+        hipLaunchKernelGGL(pt::shade_probe_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_materials, op, din, n, dout);
+    else
+        hipLaunchKernelGGL(pt::shade_probe_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_materials, op, din, n, dout);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, dout, no, hipMemcpyDeviceToHost));
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return PTRT_OK;
+}
+
 } // extern "C"
 
 #include "ptrt_farm.hip.h"

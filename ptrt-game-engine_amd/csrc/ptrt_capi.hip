@@ -2474,6 +2474,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     c->prev_stream = c->stream;
     c->touched = false;
     c->last_mode = 0;
+    c->launch_timed[slot] = 0; // (launch_trace sets it for the launches it puts events around; the other loop shapes leave none)
     if (async_applicable(c)) {
         if (int rc = run_async(c, K, full))
             return rc;

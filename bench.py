@@ -319,11 +319,15 @@ class Farm:
         while self.tuning_frames < 16 and not self.scene.get_option("merged_decided"):
             self.step()
             self.tuning_frames += 1
+        # events around every launch of the timed frames, on the stream the launch runs on (ptrt_launch_ms_history): overlapping
+        # frames are two launches each on auxiliary streams, and what the roofline is priced on is THOSE launches.  (Switched on
+        # in front of the ramp frames, so that the events exist before the timed region starts.)
+        self.scene.set_option("time_launches", 1 if time_launches else 0)
         self.ramp_ms = []
         self.ramp_frames = self.ramp() if ramp else 0
-        # events around every launch of the timed frames, on the stream the launch runs on (ptrt_launch_ms_history): overlapping
-        # frames are two launches each on auxiliary streams, and what the roofline is priced on is THOSE launches
-        self.scene.set_option("time_launches", 1 if time_launches else 0)
+        if not ramp and time_launches:
+            for _ in range(2):
+                self.step()
         self.fence()
         self.scene.stats()  # reset counters
         t0 = time.perf_counter()

@@ -537,6 +537,9 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)
  *   lds_pad 0..32768      spare bytes of LDS per workgroup: fewer waves per CU (A/B of the occupancy)
  *   wavefront 0|1, async_lanes 0|1, shade_min 1..64   the alternative loop shapes of DESIGN.md 3.9
+ *   wf_sort 0|1|2|4       wavefront stages: the shade stage bins 1 / 2 / 4 groups of 256 consecutive paths by class (finished,
+ *                         regenerating, miss, hit mesh x specular flag x roulette) in LDS before shading them -- active-path
+ *                         sorting; same bits; measured slower than unsorted, default 0
  *   time_kernels 0|1      1 (default): two events around the trace kernel feed ptrt_kernel_ms_history / ptrt_last_kernel_ms
  *   time_launches 0|1     1: three events around every launch of a frame that is dealt to the auxiliary streams ("pipeline"), on the
  *                         stream the launch runs on: ptrt_launch_ms_history (default 0: six more driver calls per frame)

@@ -1,28 +1,26 @@
-# GPU box, repo root: one line per workload -> stdout (the rows of DESIGN.md section 6).  --warmup 12 covers the frames on
-# which a queue-mode scene samples its two loop shapes (bench.py adds them anyway: Farm.measure).
-mkdir -p gpurun_out/r3x; cd gpurun_out/r3x; B="python ../../bench.py"
-$B --steps 100 --warmup 40 > default.json 2> default.err
-$B --config showcase1080 --steps 60 --warmup 40 > showcase1080.json 2>/dev/null
-$B --config showcase4k8 --steps 8 --warmup 12 --no-cpu-baseline > showcase4k8.json 2>/dev/null
-$B --config fluid --steps 100 --warmup 40 > fluid.json 2>/dev/null
-$B --config fluid --steps 100 --warmup 40 --rebuild --no-cpu-baseline > fluid_rebuild.json 2>/dev/null
-$B --scene many --steps 10 --warmup 4 --no-cpu-baseline --no-configs3 > many.json 2>/dev/null
-$B --preset balanced --steps 100 --warmup 40 --no-cpu-baseline > cornell_balanced.json 2>/dev/null
-$B --preset performance --steps 100 --warmup 40 --no-cpu-baseline > cornell_performance.json 2>/dev/null
-$B --present 2 --steps 100 --warmup 40 --no-cpu-baseline --no-configs3 > present2.json 2>/dev/null
-$B --farm 8 --steps 100 --warmup 40 --no-cpu-baseline --no-configs3 > farm8.json 2>/dev/null
-$B --config showcase1080 --opt merged=1 --opt steal=0 --steps 60 --warmup 40 --no-cpu-baseline > showcase_merged.json 2>/dev/null
-$B --config showcase1080 --opt merged=0 --steps 60 --warmup 40 --no-cpu-baseline > showcase_separate.json 2>/dev/null
-$B --config showcase1080 --opt lds_nodes=1 --steps 60 --warmup 40 --no-cpu-baseline > showcase_ldsnodes.json 2>/dev/null
-$B --config showcase1080 --opt wavefront=1 --steps 10 --warmup 4 --no-cpu-baseline > showcase_wavefront.json 2>/dev/null
-for p in fast performance balanced quality; do $B --config million --preset $p --steps 60 --warmup 40 --no-cpu-baseline > million_$p.json 2>/dev/null; done
-$B --config million --preset ultra --steps 2 --warmup 1 --no-cpu-baseline > million_ultra.json 2>/dev/null
-for f in *.json; do python - $f <<'PY'
-import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
-    c=d["config"]; r=d["roofline"]
-    print(f'{sys.argv[1]:28s} {d["ms_per_step"]:9.4f} ms  {d["fps"]:8.2f} fps  {d["value"]:10.1f} Mrays/s  kernel {r["kernel_ms"]}  valu {r["valu_issue_frac"]}  {c["workload"]} | {c["kernel"]}', c.get("present_ms_per_frame",""), c.get("farm_ms_per_frame",""), (d.get("configs3") or {}).get("ms_per_step",""), (d.get("cpu_baseline") or {}).get("value",""), ((d.get("cpu_baseline") or {}).get("single_thread") or {}).get("value",""), ((d.get("cpu_baseline") or {}).get("all_core") or {}).get("value",""))
-except Exception as e: print(sys.argv[1], "ERR", e)
+#!/bin/bash
+# GPU box, repo root: the commands behind round 4's end-of-round tables.  Output under gpurun_out/final_r04/.
+O=gpurun_out/final_r04; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -2 $O/tests.log
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/headline_driver_style.json 2> $O/err.txt            # Cornell 1080p + configs3 + cpu_baseline
+python3 bench.py > $O/headline_40_100.json 2>> $O/err.txt
+for c in showcase1080 showcase4k8 fluid; do python3 bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $O/$c.json 2>> $O/err.txt; done
+python3 bench.py --config fluid --via-commit --steps 20 --warmup 5 --no-cpu-baseline > $O/fluid_commit.json 2>> $O/err.txt
+python3 bench.py --config fluid --rebuild --steps 20 --warmup 5 --no-cpu-baseline > $O/fluid_rebuild.json 2>> $O/err.txt
+python3 bench.py --scene many --steps 20 --warmup 5 --no-cpu-baseline > $O/many.json 2>> $O/err.txt
+for p in fast performance balanced quality ultra; do python3 bench.py --config million --preset $p --steps 6 --warmup 3 --no-cpu-baseline > $O/million_$p.json 2>> $O/err.txt; done
+python3 bench.py --preset balanced --steps 20 --warmup 5 --no-cpu-baseline > $O/cornell_balanced.json 2>> $O/err.txt
+python3 bench.py --preset balanced --opt atrous_exp=1 --steps 20 --warmup 5 --no-cpu-baseline > $O/cornell_balanced_fast_exp.json 2>> $O/err.txt
+python3 bench.py --preset performance --steps 20 --warmup 5 --no-cpu-baseline > $O/cornell_performance.json 2>> $O/err.txt
+python3 bench.py --present 2 --steps 20 --warmup 5 --no-cpu-baseline --no-configs3 > $O/cornell_present2.json 2>> $O/err.txt
+python3 bench.py --farm 8 --steps 20 --warmup 5 --no-cpu-baseline --no-configs3 > $O/cornell_farm8.json 2>> $O/err.txt
+# A/B of this round's options on overlapping frames (tools/ab.py): stealing on / off in both loop shapes
+python tools/ab.py showcase1080 "merged=0,csteal=0" "merged=0" "merged=1,csteal=0" "merged=1" > $O/ab_showcase.txt 2>&1
+python tools/ab.py cornell1080 "" "tm_prio=1" "tm_prio=2" "refill=0" > $O/ab_cornell.txt 2>&1
+for f in $O/*.json; do python3 - "$f" <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
+print(f"{sys.argv[1].split('/')[-1]:36s} {d['ms_per_step']:9.4f} ms  {d['fps']:9.2f} fps  {d['value']:10.1f} Mrays/s  {d['config']['kernel'][:70]}", d.get("configs3", {}).get("ms_per_step", ""), d["config"].get("fluid_sources", ""), d["config"].get("present_ms_per_frame", ""), d["config"].get("farm_ms_per_frame", ""))
 PY
-done
+done | tee $O/table.txt
+grep -v amdgpu.ids $O/ab_showcase.txt $O/ab_cornell.txt

@@ -2192,53 +2192,14 @@ int ptrt_set_bloom(ptrt_ctx *c, int enabled) {
     return PTRT_OK;
 }
 
-int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
-    if (!ctx_live(c, false))
-        return fail(c, PTRT_E_INVALID, "ptrt_render: bad context");
-    if (!c->have_geometry || !c->have_materials)
-        return fail(c, PTRT_E_NOT_READY, "ptrt_render: %s not uploaded", c->have_geometry ? "materials" : "geometry");
-    if (c->n_materials < c->n_meshes)
-        return fail(c, PTRT_E_NOT_READY, "ptrt_render: %d materials for %d meshes", c->n_materials, c->n_meshes);
-    if (!c->rng_ready)
-        return fail(c, PTRT_E_NOT_READY, "ptrt_render: generator states not initialised (ptrt_reset_rng)");
-    if (spp < 1 || max_depth < 1 || spp > 32767 || max_depth > 32767) // (a lane keeps its sample index and bounce in one register's halves)
-        return fail(c, PTRT_E_INVALID, "ptrt_render: spp=%d max_depth=%d (1..32767)", spp, max_depth);
-    if (frame_index < 0 || frame_index > INT_MAX - spp) // (sample s of the frame indexes the jitter table with (frame_index + s) % 16)
-        return fail(c, PTRT_E_INVALID, "ptrt_render: frame_index=%d", frame_index);
-    if (int rc = set_device(c))
-        return rc;
-    pt::KParams K = make_params(c);
-    K.spp = spp;
-    K.max_depth = max_depth;
-    // Samples in step (path_trace_kernel [A], K.sample_sync): the lanes of a wave start a sample together, so a wave's lanes sit at the
-    // same bounce -- a first hit samples no light and the whole wave skips [C2] / [D] in that iteration, [A] runs once per sample
-    // for 64 lanes instead of every iteration for a quarter of them -- at the price of lanes that wait for the longest path of
-    // the sample.  Pays while most paths run to the depth limit: Cornell 4 bounces 1.764 -> 1.638 ms (3 bounces 1.42 -> 1.26),
-    // `many` 15.9 -> 14.8; loses once Russian roulette thins the wave (5 bounces 1.966 -> 1.980, 6: 2.10 -> 2.31, 8: 2.26 ->
-    // 2.80); scenes of short paths are indifferent once a path's last vertex costs nothing (showcase 3.90 -> 3.90; the fluid frame
-    // gains 3 %), so the depth limit alone decides.  Releasing the waiting lanes early
-    // (when few are still under way, or when many wait) was measured at every threshold and is worse than both extremes.
-    K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : (max_depth <= 4 ? 1 : 0);
-    c->sample_sync_eff = K.sample_sync;
-    K.frame_count = frame_index;
-    unsigned char *frame_rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
-    // the stage that produces the final HDR image also tonemaps it; earlier stages skip theirs
-    const bool scaled = c->scaled(), denoise = c->dn_on && c->dn_active, bloom = c->bloom_on != 0;
-    // PTRT_OUT_DEVICE_FRAME: out_rgb8 is the whole W x H frame on this device; a band / strip context writes its rows where
-    // they belong in it -- no image of its own, nothing for a tile farm to copy (ptrt_farm_*)
-    const bool into_frame = out_rgb8 && out_is_device == PTRT_OUT_DEVICE_FRAME;
-    if (into_frame && (denoise || bloom || scaled))
-        return fail(c, PTRT_E_INVALID, "ptrt_render: PTRT_OUT_DEVICE_FRAME with the denoiser, bloom or a reduced render size");
-    c->last_rgb8 = into_frame ? nullptr : frame_rgb8; // (a frame target is the caller's: ptrt_read_buffer(RGB8) has nothing to read)
-    c->last_frame_target = into_frame ? out_rgb8 : nullptr;
-    K.rgb8_frame = into_frame ? 1 : 0;
-    K.rgb8 = (denoise || bloom || scaled) ? nullptr : frame_rgb8;
-    if (c->count_rays)
-        K.counters = c->d_counters;
-    const int tiles_y = (K.rows + 7) / 8;
-    const int grid = K.tiles_x * tiles_y;
-    const int geom = pick_geom(c);
-    const bool full = c->mats_full || c->force_full;
+} // extern "C"
+
+namespace {
+
+// ---- ptrt_render, step by step ----------------------------------------------------------------------------------------
+// Which of the two exact shapes of the queue modes' loop this frame runs (option "merged"); true while the choice is being
+// sampled (the frame's launch is then timed and ordered behind the stream).
+bool choose_loop_shape(ptrt_ctx *c, int spp, int max_depth, int geom) {
     // merged = -1: the two exact shapes of the queue modes' loop (shadow rays in their own traversal, or riding with the next
     // extension rays) take turns over a scene's frames 4-7 (the first four warm the clocks up); their kernel times (the event
     // ring) decide the rest at frame 8, which waits for frame 7 once
@@ -2289,29 +2250,18 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
             c->merged_eff = c->tune_choice;
         }
     }
-    const int pmode = pair_mode(c, geom, c->merged_eff != 0);
-    c->last_pmode = pmode;
-    // (round 2: the merged loop was at its best WITHOUT shadow-ray subtree stealing, 3.98 vs 4.17 ms on the showcase frame -- its
-    // yields served ten shadow pairs at the price of sixty closest-hit walks; with the closest-hit walks stolen from as well the
-    // yields pay for both kinds: 3.19 ms with, 3.49 without)
-    if (c->merged < 0 && pmode == 4 && c->csteal == 0)
-        K.steal = 0;
-    const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
-    // (the heads only change with the mesh records: a frame since whose predecessor no entry point touched the device keeps them)
-    if (pmode == 3 && (c->touched || !c->heads_fresh)) { // (outside the timed kernel: a 136-thread copy)
-        c->heads_fresh = true;
-        hipLaunchKernelGGL(pt::gather_tlas_heads_kernel, dim3((c->n_tlas_index + 63) / 64), dim3(64), 0, c->stream,
-                           c->d_mesh_recs, c->d_inst_pre, c->d_tlas_mesh_ids, c->n_tlas_index, c->d_tlas_heads,
-                           c->inst_pre_ok ? 1 : 0);
-        HIP_TRY(c, hipGetLastError());
-    }
+    return tuning;
+}
+
+// PMODE 1: LDS layout of a workgroup (pt::carve_pm1) -> its size in bytes; fills K.lds_* and the tiles per workgroup.
+size_t pm1_layout(ptrt_ctx *c, pt::KParams &K, bool full, int grid, int &pm1_wg) {
+    size_t lds_main = 0;
+    pm1_wg = 1;
     // PMODE 1 (pt::carve_pm1): the read-only copies are per workgroup, the lists per wave.  With the simple materials the
     // kernel exists for one tile per workgroup at five waves per SIMD and for TWO tiles at six (option pm1_wg: 0 = the larger
     // one if the scene fits its LDS budget, 1 / 2 force); the shading inputs are staged piece by piece while the workgroup
     // stays within the budget of the occupancy its kernel is built for.
-    size_t lds_main = lds + (size_t)c->lds_pad;
-    int pm1_wg = 1;
-    if (pmode == 1) {
+    {
         const size_t shared0 = (size_t)c->pair_tri_slots * 48 + (size_t)c->pair_meshes * (pt::PAIR_PAD * 16 + 16 + 32);
         const size_t lights = (size_t)c->n_lights * 64, mats = (size_t)c->pair_meshes * (full ? 96 : 48);
         // (the lanes' blue-noise slots, 512 bytes per wave, are only worth their LDS while [A] runs in every iteration: with the
@@ -2357,13 +2307,18 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         lds_main = need;
         K.n_tiles = grid;
     }
-    if (c->launches == 0 && getenv("PTRT_DEBUG_LDS"))
-        fprintf(stderr, "ptrt: pmode %d, %d meshes in the leaf, %d triangle slots, stack %d, LDS %zu + %zu bytes per workgroup\n", pmode,
-                c->pair_meshes, c->pair_tri_slots, c->stack_entries, lds, lds_main - lds);
-    const int slot = (int)(c->launches % EV_RING);
-    const bool timing = c->time_kernels || tuning;
-    if (timing)
-        HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
+    return lds_main;
+}
+
+// Whether this frame may overlap its predecessor on the device, and the waits that make it safe.  Sets c->split_eff /
+// c->pipelined_last, swaps in the second HDR / G-buffer set for a frame with a post chain, records the stream's head for the
+// next frame.  `splittable`: the frame's kernel can be dealt to several launches at all; `recording`: the caller is capturing
+// the stream into a hipGraph.
+struct OverlapPlan {
+    bool splittable = false, recording = false;
+};
+int plan_overlap(ptrt_ctx *c, pt::KParams &K, int spp, int max_depth, int pmode, int pm1_wg, int tiles_y, bool tuning, bool scaled, bool post,
+                 void *out_rgb8, int out_is_device, OverlapPlan &plan) {
     // Options "split" / "pipeline": frame pipelining.  A frame ends with a tail -- its last waves drain while most of the chip
     // idles, then the next launch ramps up: ~8 % of a 1080p Cornell frame.  With the frame's rows of tiles dealt to `split`
     // launches on auxiliary streams, launch i of frame N + 1 touches the same pixels (generator states, accumulators, image
@@ -2394,7 +2349,6 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
             (void)hipGetLastError();
         recording = cs != hipStreamCaptureStatusNone;
     }
-    const bool post = denoise || bloom;
     // (the previous frame's post chain reads the HDR image and G-buffers this frame's trace would overwrite: a frame WITH a chain
     // writes the other set, below; one without -- the chain was switched off in between -- waits for the stream instead.  A
     // changed number of launches moves the rows between the auxiliary streams: only a one-launch frame may precede it.)
@@ -2460,21 +2414,14 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         HIP_TRY(c, hipEventRecord(he, c->stream));
         ++c->head_n;
     }
-    // Lane refill (launch_trace): where it was measured to pay.  Overlapping 1080p Cornell frames 1.67 -> 1.62 ms, 8 bounces 2.12
-    // -> 1.88, 4K 6.65 -> 6.27; a frame alone on the chip ends in a long drain of half-empty persistent waves (1.81 -> 1.97),
-    // short pixels finish before the refill pays for itself (1 spp: 0.43 -> 0.61), and beside a post chain the persistent waves
-    // keep the chain's kernels waiting for a place on the chip (balanced preset 2.41 -> 2.50).
-    // (And a launch must hold at least two tiles per persistent wave -- 1280 x 720 measured even, smaller frames lose.)
-    const long per_launch = (long)grid / (c->split_eff > 1 ? c->split_eff : 1);
-    const long resident = (long)c->n_cus * (c->persist > 0 ? c->persist : 4 * pt::waves_per_simd(1, full, 1));
-    c->refill_eff = pmode == 1 && pm1_wg == 1 &&
-                    (c->refill == 2 || (c->refill == 1 && c->pipelined_last && !full && !denoise && !bloom &&
-                                        (long)spp * max_depth >= 16 && per_launch >= 2 * resident));
-    c->prev_out = (out_rgb8 && out_is_device) ? out_rgb8 : nullptr;
-    c->prev_stream = c->stream;
-    c->touched = false;
-    c->last_mode = 0;
-    c->launch_timed[slot] = 0; // (launch_trace sets it for the launches it puts events around; the other loop shapes leave none)
+    plan.splittable = splittable;
+    plan.recording = recording;
+    return PTRT_OK;
+}
+
+// The frame's trace launch(es) in the loop shape chosen for the scene.
+int launch_frame(ptrt_ctx *c, pt::KParams &K, bool full, int spp, int max_depth, int geom, int pmode, int pm1_wg, int grid, size_t lds,
+                 size_t lds_main) {
     if (async_applicable(c)) {
         if (int rc = run_async(c, K, full))
             return rc;
@@ -2515,6 +2462,12 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     else
         { if (int rc = launch_trace<2, 0>(c, K, full, grid, lds)) return rc; }
     HIP_TRY(c, hipGetLastError());
+    return PTRT_OK;
+}
+
+// Joins a split frame onto the context's stream and notes what the NEXT frame may follow.
+int join_frame(ptrt_ctx *c, const OverlapPlan &plan, bool post) {
+    const bool splittable = plan.splittable, recording = plan.recording;
     for (int i = 0; c->split_eff > 1 && i < c->split_eff; ++i) { // join: what follows on the context's stream follows every launch
         HIP_TRY(c, hipEventRecord(c->split_join[i], c->aux_stream[i]));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->split_join[i], 0));
@@ -2531,6 +2484,114 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
         HIP_TRY(c, hipEventRecord(c->split_fork, c->stream));
         c->prev_split = 1;
     }
+    return PTRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device) {
+    if (!ctx_live(c, false))
+        return fail(c, PTRT_E_INVALID, "ptrt_render: bad context");
+    if (!c->have_geometry || !c->have_materials)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_render: %s not uploaded", c->have_geometry ? "materials" : "geometry");
+    if (c->n_materials < c->n_meshes)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_render: %d materials for %d meshes", c->n_materials, c->n_meshes);
+    if (!c->rng_ready)
+        return fail(c, PTRT_E_NOT_READY, "ptrt_render: generator states not initialised (ptrt_reset_rng)");
+    if (spp < 1 || max_depth < 1 || spp > 32767 || max_depth > 32767) // (a lane keeps its sample index and bounce in one register's halves)
+        return fail(c, PTRT_E_INVALID, "ptrt_render: spp=%d max_depth=%d (1..32767)", spp, max_depth);
+    if (frame_index < 0 || frame_index > INT_MAX - spp) // (sample s of the frame indexes the jitter table with (frame_index + s) % 16)
+        return fail(c, PTRT_E_INVALID, "ptrt_render: frame_index=%d", frame_index);
+    if (int rc = set_device(c))
+        return rc;
+    pt::KParams K = make_params(c);
+    K.spp = spp;
+    K.max_depth = max_depth;
+    // Samples in step (path_trace_kernel [A], K.sample_sync): the lanes of a wave start a sample together, so a wave's lanes sit at the
+    // same bounce -- a first hit samples no light and the whole wave skips [C2] / [D] in that iteration, [A] runs once per sample
+    // for 64 lanes instead of every iteration for a quarter of them -- at the price of lanes that wait for the longest path of
+    // the sample.  Pays while most paths run to the depth limit: Cornell 4 bounces 1.764 -> 1.638 ms (3 bounces 1.42 -> 1.26),
+    // `many` 15.9 -> 14.8; loses once Russian roulette thins the wave (5 bounces 1.966 -> 1.980, 6: 2.10 -> 2.31, 8: 2.26 ->
+    // 2.80); scenes of short paths are indifferent once a path's last vertex costs nothing (showcase 3.90 -> 3.90; the fluid frame
+    // gains 3 %), so the depth limit alone decides.  Releasing the waiting lanes early
+    // (when few are still under way, or when many wait) was measured at every threshold and is worse than both extremes.
+    K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : (max_depth <= 4 ? 1 : 0);
+    c->sample_sync_eff = K.sample_sync;
+    K.frame_count = frame_index;
+    unsigned char *frame_rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
+    // the stage that produces the final HDR image also tonemaps it; earlier stages skip theirs
+    const bool scaled = c->scaled(), denoise = c->dn_on && c->dn_active, bloom = c->bloom_on != 0;
+    // PTRT_OUT_DEVICE_FRAME: out_rgb8 is the whole W x H frame on this device; a band / strip context writes its rows where
+    // they belong in it -- no image of its own, nothing for a tile farm to copy (ptrt_farm_*)
+    const bool into_frame = out_rgb8 && out_is_device == PTRT_OUT_DEVICE_FRAME;
+    if (into_frame && (denoise || bloom || scaled))
+        return fail(c, PTRT_E_INVALID, "ptrt_render: PTRT_OUT_DEVICE_FRAME with the denoiser, bloom or a reduced render size");
+    c->last_rgb8 = into_frame ? nullptr : frame_rgb8; // (a frame target is the caller's: ptrt_read_buffer(RGB8) has nothing to read)
+    c->last_frame_target = into_frame ? out_rgb8 : nullptr;
+    K.rgb8_frame = into_frame ? 1 : 0;
+    K.rgb8 = (denoise || bloom || scaled) ? nullptr : frame_rgb8;
+    if (c->count_rays)
+        K.counters = c->d_counters;
+    const int tiles_y = (K.rows + 7) / 8;
+    const int grid = K.tiles_x * tiles_y;
+    const int geom = pick_geom(c);
+    const bool full = c->mats_full || c->force_full;
+    // merged = -1: the two exact shapes of the queue modes' loop take turns over a scene's first frames and the faster one stays
+    const bool tuning = choose_loop_shape(c, spp, max_depth, geom);
+    const int pmode = pair_mode(c, geom, c->merged_eff != 0);
+    c->last_pmode = pmode;
+    // (round 2: the merged loop was at its best WITHOUT shadow-ray subtree stealing, 3.98 vs 4.17 ms on the showcase frame -- its
+    // yields served ten shadow pairs at the price of sixty closest-hit walks; with the closest-hit walks stolen from as well the
+    // yields pay for both kinds: 3.19 ms with, 3.49 without)
+    if (c->merged < 0 && pmode == 4 && c->csteal == 0)
+        K.steal = 0;
+    const size_t lds = pmode ? pair_lds_bytes(c, pmode) : ((geom == 0) ? 0 : (size_t)c->stack_entries * 64 * sizeof(uint2));
+    // (the heads only change with the mesh records: a frame since whose predecessor no entry point touched the device keeps them)
+    if (pmode == 3 && (c->touched || !c->heads_fresh)) { // (outside the timed kernel: a 136-thread copy)
+        c->heads_fresh = true;
+        hipLaunchKernelGGL(pt::gather_tlas_heads_kernel, dim3((c->n_tlas_index + 63) / 64), dim3(64), 0, c->stream,
+                           c->d_mesh_recs, c->d_inst_pre, c->d_tlas_mesh_ids, c->n_tlas_index, c->d_tlas_heads,
+                           c->inst_pre_ok ? 1 : 0);
+        HIP_TRY(c, hipGetLastError());
+    }
+    // PMODE 1: the workgroup's LDS layout (triangles, tables and -- while the budget of its occupancy lasts -- the shading inputs)
+    size_t lds_main = lds + (size_t)c->lds_pad;
+    int pm1_wg = 1;
+    if (pmode == 1)
+        lds_main = pm1_layout(c, K, full, grid, pm1_wg);
+    if (c->launches == 0 && getenv("PTRT_DEBUG_LDS"))
+        fprintf(stderr, "ptrt: pmode %d, %d meshes in the leaf, %d triangle slots, stack %d, LDS %zu + %zu bytes per workgroup\n", pmode,
+                c->pair_meshes, c->pair_tri_slots, c->stack_entries, lds, lds_main - lds);
+    const int slot = (int)(c->launches % EV_RING);
+    const bool timing = c->time_kernels || tuning;
+    if (timing)
+        HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot], c->stream));
+    // frame pipelining (options "split" / "pipeline"): may this frame's launches follow the previous frame's instead of the stream?
+    const bool post = denoise || bloom;
+    OverlapPlan plan;
+    if (int rc = plan_overlap(c, K, spp, max_depth, pmode, pm1_wg, tiles_y, tuning, scaled, post, out_rgb8, out_is_device, plan))
+        return rc;
+    // Lane refill (launch_trace): where it was measured to pay.  Overlapping 1080p Cornell frames 1.67 -> 1.62 ms, 8 bounces 2.12
+    // -> 1.88, 4K 6.65 -> 6.27; a frame alone on the chip ends in a long drain of half-empty persistent waves (1.81 -> 1.97),
+    // short pixels finish before the refill pays for itself (1 spp: 0.43 -> 0.61), and beside a post chain the persistent waves
+    // keep the chain's kernels waiting for a place on the chip (balanced preset 2.41 -> 2.50).
+    // (And a launch must hold at least two tiles per persistent wave -- 1280 x 720 measured even, smaller frames lose.)
+    const long per_launch = (long)grid / (c->split_eff > 1 ? c->split_eff : 1);
+    const long resident = (long)c->n_cus * (c->persist > 0 ? c->persist : 4 * pt::waves_per_simd(1, full, 1));
+    c->refill_eff = pmode == 1 && pm1_wg == 1 &&
+                    (c->refill == 2 || (c->refill == 1 && c->pipelined_last && !full && !denoise && !bloom &&
+                                        (long)spp * max_depth >= 16 && per_launch >= 2 * resident));
+    c->prev_out = (out_rgb8 && out_is_device) ? out_rgb8 : nullptr;
+    c->prev_stream = c->stream;
+    c->touched = false;
+    c->last_mode = 0;
+    c->launch_timed[slot] = 0; // (launch_trace sets it for the launches it puts events around; the other loop shapes leave none)
+    if (int rc = launch_frame(c, K, full, spp, max_depth, geom, pmode, pm1_wg, grid, lds, lds_main))
+        return rc;
+    if (int rc = join_frame(c, plan, post))
+        return rc;
     if (timing)
         HIP_TRY(c, hipEventRecord(c->ev_ring[2 * slot + 1], c->stream));
     if (tuning) {

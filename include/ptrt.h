@@ -452,12 +452,16 @@ int ptrt_post_frame(ptrt_ctx *ctx, const float *accum, const float *normal, cons
  *                     loaded or ncclCommInitAll fails, with PTRT_FARM_TRANSPORT=peer in the environment, or after
  *                     ptrt_farm_set_option(farm, "transport", 1) (0 = back to RCCL, refused if its communicators never came
  *                     up).  Errors: ptrt_last_error(NULL).
- * The "rccl" AND "peer-copy" transports are UNVERIFIED ON HARDWARE (every test so far ran on a one-GPU box).  A presentation-ring slot as the
+ * The "rccl" transport is UNVERIFIED ON HARDWARE (every test so far ran on a one-GPU box); "peer-copy" has run with equal source
+ * and destination device only (PTRT_FARM_FORCE_REMOTE=1: a test hook that makes a farm treat every part but the first as remote).  A presentation-ring slot as the
  * device target (rtgl::map_pbo_device_ptr) is recognised: its download is ordered behind the gather's copies. */
 typedef struct ptrt_farm ptrt_farm;
 int ptrt_farm_create(ptrt_ctx *const *contexts, int n_contexts, ptrt_farm **out);
 int ptrt_farm_bands(const ptrt_farm *farm);
 const char *ptrt_farm_transport(const ptrt_farm *farm);
+/* ABI 6: 1 if part `part` sits on the presenting device (it may render straight into the frame the gather assembles:
+ * ptrt_render(..., frame, PTRT_OUT_DEVICE_FRAME)), 0 if its image has to travel (render it with a NULL target) */
+int ptrt_farm_part_is_local(const ptrt_farm *farm, int part);
 int ptrt_farm_render(ptrt_farm *farm, int frame_index, int spp, int max_depth, void *out_rgb8, int out_is_device);
 int ptrt_farm_gather(ptrt_farm *farm, void *out_rgb8, int out_is_device);
 /* ABI 5.  The per-part host work of a frame runs on one worker thread per context (a ptrt_render costs 20-50 us of host

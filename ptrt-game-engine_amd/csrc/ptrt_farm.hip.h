@@ -279,10 +279,14 @@ int ptrt_farm_create(ptrt_ctx *const *bands, int n_bands, ptrt_farm **out) {
     if (e != hipSuccess)
         return bail(PTRT_E_HIP, hipGetErrorString(e));
     // devices other than the presenting one talk to it over RCCL: one communicator per distinct device
+    // (PTRT_FARM_FORCE_REMOTE=1, a test hook: every context but the first is treated like one on another device -- an image of its
+    // own, a staging buffer, the peer-copy transport -- even on the presenting device, so that a one-GPU box executes that path:
+    // hipMemcpyPeerAsync with equal source and destination device, the rendered / taken events, the strided placement)
+    const bool force_remote = getenv("PTRT_FARM_FORCE_REMOTE") != nullptr;
     f->comm_dev.push_back(f->device);
     for (int i = 0; i < n_bands; ++i) {
         const int d = bands[i]->device;
-        if (d == f->device)
+        if (d == f->device && !(force_remote && i > 0))
             continue;
         size_t k = 0;
         while (k < f->comm_dev.size() && f->comm_dev[k] != d)
@@ -290,11 +294,11 @@ int ptrt_farm_create(ptrt_ctx *const *bands, int n_bands, ptrt_farm **out) {
         if (k == f->comm_dev.size())
             f->comm_dev.push_back(d);
         f->comm_rank[(size_t)i] = (int)k;
-    }
-    if (f->comm_dev.size() > 1) {
         f->remote = true;
+    }
+    if (f->remote) {
         const char *want = getenv("PTRT_FARM_TRANSPORT");
-        const bool want_peer = want && std::string(want) == "peer";
+        const bool want_peer = force_remote || (want && std::string(want) == "peer");
         if (!want_peer) {
             if (!rccl().ok) {
                 f->rccl_error = "librccl.so could not be loaded";
@@ -348,6 +352,11 @@ int ptrt_farm_create(ptrt_ctx *const *bands, int n_bands, ptrt_farm **out) {
 }
 
 int ptrt_farm_bands(const ptrt_farm *f) { return farm_live(const_cast<ptrt_farm *>(f)) ? (int)f->band.size() : 0; }
+
+// 1: part i sits on the presenting device and may render straight into the frame (PTRT_OUT_DEVICE_FRAME); 0: its image travels
+int ptrt_farm_part_is_local(const ptrt_farm *f, int i) {
+    return farm_live(const_cast<ptrt_farm *>(f)) && i >= 0 && i < (int)f->band.size() && f->comm_rank[(size_t)i] < 0 ? 1 : 0;
+}
 
 const char *ptrt_farm_transport(const ptrt_farm *f) { return farm_live(const_cast<ptrt_farm *>(f)) ? f->transport.c_str() : ""; }
 

@@ -94,7 +94,7 @@ class TileFarm {
             TileFarm *self = static_cast<TileFarm *>(u);
             try {
                 Scene &p = *self->parts[(size_t)i];
-                if (self->dev_frame && p.deviceIndex() == self->parts[0]->deviceIndex())
+                if (self->dev_frame && ptrt_farm_part_is_local(self->farm, i))
                     p.render_to_frame(self->dev_frame);
                 else
                     p.render_to_device(nullptr);

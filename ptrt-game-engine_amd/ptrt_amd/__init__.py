@@ -172,6 +172,7 @@ _sig("ptrt_create_interleaved", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c
 _sig("ptrt_farm_create", C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp))
 _sig("ptrt_farm_bands", C.c_int, _vp)
 _sig("ptrt_farm_transport", C.c_char_p, _vp)
+_sig("ptrt_farm_part_is_local", C.c_int, _vp, C.c_int)
 _sig("ptrt_farm_render", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int)
 _sig("ptrt_farm_gather", C.c_int, _vp, _vp, C.c_int)
 _sig("ptrt_farm_sync", C.c_int, _vp)

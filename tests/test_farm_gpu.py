@@ -218,3 +218,31 @@ def test_contexts_write_their_rows_straight_into_one_frame(P):
     assert P.lib.ptrt_render(s.ctx, 1, 1, 4, C.c_void_p(frame.data_ptr()), 2) == -1
     assert b"PTRT_OUT_DEVICE_FRAME" in P.lib.ptrt_last_error(s.ctx)
     s.close()
+
+
+def test_peer_copy_transport_executes_on_one_gpu(P):
+    """The peer-copy transport (hipMemcpyPeerAsync of a part's image into the presenting device's staging buffer behind the part's
+    `rendered` event, its next render behind a `taken` event, then the placement of bands / strips) has no second device to run
+    between here -- PTRT_FARM_FORCE_REMOTE=1 makes the farm treat every part but the first as if it sat on another device, so the
+    whole path executes on this one GPU (source device == destination device) and must assemble the full-frame context's bytes,
+    frame after frame.  What stays UNVERIFIED ON HARDWARE is only the copy between two different devices."""
+    import os
+    W, H, n = 192, 104, 4
+    build = lambda s: P.scenes.showcase(s, segments=8)
+    full = P.Scene(W, H)
+    _prep(P, full, build)
+    want = [full.render_to_host() for _ in range(3)]
+    full.close()
+    for strips in (True, False):
+        os.environ["PTRT_FARM_FORCE_REMOTE"] = "1"
+        try:
+            farm = P.TileFarm(W, H, [0] * n, strips=strips)
+        finally:
+            del os.environ["PTRT_FARM_FORCE_REMOTE"]
+        assert farm.transport == "peer-copy"
+        for sc in farm.scenes:
+            _prep(P, sc, build)
+        for f in range(3):
+            got = farm.render_to_host()
+            assert np.array_equal(got, want[f]), f"{'strips' if strips else 'bands'}, frame {f}"
+        farm.close()

@@ -13,9 +13,10 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, SPP, DEPTH = 48, 39, 2, 3
+SIZE8 = (40, 77)  # the world-8 case: ten 8-row strips (two ranks own two), bands of 9 rows and one of 14
 
 
-def _strip_worker(rank, world, port, out_path):
+def _strip_worker(rank, world, port, out_path, W=W, H=H):
     """The strip layout (every world-th 8-row strip per rank, images padded to one size, one gather, rank 0 scatters)."""
     for p in (os.path.join(ROOT, "ptrt-game-engine_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
@@ -53,7 +54,7 @@ def _strip_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, W=W, H=H):
     for p in (os.path.join(ROOT, "ptrt-game-engine_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     import oracle as O
@@ -84,15 +85,18 @@ def _free_port():
 
 
 @pytest.mark.parametrize("layout", ["bands", "strips"])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_tile_farm_assembles_the_single_process_frame(P, O, blue_noise, tmp_path, world, layout):
+    """(world 8 = BASELINE configs[3]'s partitioning: eight ranks, bands with a remainder band -- the point-to-point fallback of
+    gather_bands -- and strips of which some ranks own two and some one)"""
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker if layout == "bands" else _strip_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    w, h = SIZE8 if world == 8 else (W, H)
+    mp.spawn(_worker if layout == "bands" else _strip_worker, args=(world, _free_port(), out, w, h), nprocs=world, join=True)
     got = np.load(out)
-    s = P.Scene(W, H, device=P.HOST_ONLY)
+    s = P.Scene(w, h, device=P.HOST_ONLY)
     P.scenes.cornell(s)
-    r = O.render(s.flatten(), W, H, SPP, DEPTH, 0, blue_noise, O.xorwow_init(P.DEFAULT_SEED, 0, W * H))
-    want = O.tonemap(r["accum"], W, H)
+    r = O.render(s.flatten(), w, h, SPP, DEPTH, 0, blue_noise, O.xorwow_init(P.DEFAULT_SEED, 0, w * h))
+    want = O.tonemap(r["accum"], w, h)
     assert got.any() and np.array_equal(got, want)
 
 

@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
         const float var_scale = sqrt_ieee(max_(cvar, 1e-6f));
         const float asl = sigma_lum * (1.0f + var_scale * 2.0f);
         const float inv_sl2 = 1.0f / (2.0f * asl * asl + 1e-6f);
+        const float fast_k = -inv_sl2 * 1.44269504f; // (FAST: exp(-x) = exp2(x * -log2 e), the constant folded once per pixel)
         f3 sum = mk3(0.0f);
         float sum_var = 0.0f, total_w = 0.0f;
         // The reference's chain of early `continue`s (denoiser.cuh:686-721) as ONE predicate per tap: every operand of a tap is
@@ -466,7 +467,10 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                 const float nlum = s_l[ne];
                 bool ok = nobj != AT_OUTSIDE; // nx < 0 || nx >= W || ny < 0 || ny >= H
                 ok = ok && !(uo && cobj != nobj && cobj >= 0 && nobj >= 0);
-                const float max_d = max_(cd, ng.w);
+                // (hardware maximum: equal to max_ -- CUDA's fmaxf -- for every pair of operands that can reach the division
+                // below: a NaN operand is ignored by both, and the one case in which they differ, the sign of max(+0, -0),
+                // fails `max_d > 1e-6f` either way)
+                const float max_d = __builtin_fmaxf(cd, ng.w);
                 const float dd = __builtin_fabsf(cd - ng.w);
                 const float qa = dd * __builtin_amdgcn_rcpf(max_d);
                 bool far = qa > e_hi;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void atrous_kernel(float4 *__restrict__ out_c4
                 if (ok) {
                     const f3 nc = xyz(nc4);
                     const float ld = __builtin_fabsf(clum - nlum);
-                    const float wl = FAST ? __builtin_amdgcn_exp2f((-ld * ld * inv_sl2) * 1.44269504f) : det_exp(-ld * ld * inv_sl2);
+                    const float wl = FAST ? __builtin_amdgcn_exp2f(ld * ld * fast_k) : det_exp(-ld * ld * inv_sl2);
                     // atrous_kernel[k] = (a*b)/256 with a,b in {1,4,6}: products and the /256 are exact in fp32
                     const float weight = (KW[dy + 2] * KW[dx + 2] / 256.0f) * wl;
                     sum = sum + nc * weight;

@@ -22,6 +22,25 @@
 
 namespace pt {
 
+// Device-to-device copy of new vertex positions into the arena (ptrt_update_vertices): hipMemcpyAsync's blit took 93 us for the
+// fluid scene's 4.7 MB (50 GB/s: profiles/r04_fluid_kernel_stats.csv), a tenth of the refit + trace frame; this is a plain
+// grid-stride copy -- 16-byte lanes when both ends are 16-byte aligned, dwords otherwise.
+__global__ __launch_bounds__(256) void copy_words_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n_floats, int vec4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec4) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        const size_t n4 = n_floats / 4;
+        for (size_t i = t; i < n4; i += stride)
+            d4[i] = s4[i];
+        for (size_t i = n4 * 4 + t; i < n_floats; i += stride)
+            dst[i] = src[i];
+    } else {
+        for (size_t i = t; i < n_floats; i += stride)
+            dst[i] = src[i];
+    }
+}
+
 __global__ void repack_tris_kernel(const float *__restrict__ verts, const int4 *__restrict__ slot_face,
                                    float4 *__restrict__ tris, int n_slots) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptrt_oracle.so")
+# (PTRT_ORACLE_LIB: another build of the same sources -- tools/fmad_sensitivity.py loads the one compiled with every a*b+c
+# contracted, to estimate how far a CUDA build with nvcc's default -fmad=true may sit from this one)
+LIB_PATH = os.environ.get("PTRT_ORACLE_LIB") or os.path.join(_HERE, "libptrt_oracle.so")
 
 
 def build():

@@ -45,6 +45,11 @@ static inline float dm_min(float a, float b) { return (a < b || b != b) ? a : b;
 
 /* sin and cos of x (radians), |x| up to a few thousand. */
 static inline void dm_sincos(float x, float *s_out, float *c_out) {
+#ifdef PTRT_ORACLE_LIBM /* (tools/fmad_sensitivity.py --variant libm: the platform libm in place of the deterministic version) */
+    *s_out = sinf(x);
+    *c_out = cosf(x);
+    return;
+#endif
     const float kf = rintf(x * 0x1.45f306p-1f); /* 2/pi */
     const int k = (int)kf;
     float r = dm_fma(-kf, 0x1.921fb6p+0f, x); /* pi/2 in three pieces */
@@ -80,6 +85,9 @@ static inline float dm_cos(float x) {
 
 /* e^x */
 static inline float dm_exp(float x) {
+#ifdef PTRT_ORACLE_LIBM /* (tools/fmad_sensitivity.py --variant libm: the platform libm in place of the deterministic version) */
+    return expf(x);
+#endif
     if (x != x)
         return x;
     if (x > 88.72283f)
@@ -106,6 +114,9 @@ static inline float dm_exp(float x) {
 
 /* natural log; x <= 0 follows IEEE (log 0 = -inf, log negative = NaN) */
 static inline float dm_log(float x) {
+#ifdef PTRT_ORACLE_LIBM /* (tools/fmad_sensitivity.py --variant libm: the platform libm in place of the deterministic version) */
+    return logf(x);
+#endif
     if (x != x)
         return x;
     if (x < 0.0f)
@@ -149,7 +160,12 @@ static inline float dm_log(float x) {
 }
 
 /* x^y for x > 0 (the only use on the path: the sRGB OETF, x in (0.003,1]) */
-static inline float dm_pow(float x, float y) { return dm_exp(y * dm_log(x)); }
+static inline float dm_pow(float x, float y) {
+#ifdef PTRT_ORACLE_LIBM /* (tools/fmad_sensitivity.py --variant libm: the platform libm in place of the deterministic version) */
+    return powf(x, y);
+#endif
+    return dm_exp(y * dm_log(x));
+}
 
 /* atan for x >= 0 (Cephes atanf: two range reductions, degree-4 polynomial in x^2) */
 static inline float dm_atan_pos(float x) {
@@ -169,6 +185,9 @@ static inline float dm_atan_pos(float x) {
 }
 /* atan2f(y, x) in [-pi, pi] (sampleSky's phi, rendering/render_utils.cuh:126); NaN in -> NaN out */
 static inline float dm_atan2(float y, float x) {
+#ifdef PTRT_ORACLE_LIBM /* (tools/fmad_sensitivity.py --variant libm: the platform libm in place of the deterministic version) */
+    return atan2f(y, x);
+#endif
     if (x != x || y != y)
         return x + y;
     const float PI_F = 0x1.921fb6p+1f, PIO2_F = 0x1.921fb6p+0f;
@@ -201,6 +220,9 @@ static inline float dm_asin_core(float a, float z) { /* a + a*z*P(z) */
     return dm_fma(p * z, a, a);
 }
 static inline float dm_acos(float x) {
+#ifdef PTRT_ORACLE_LIBM /* (tools/fmad_sensitivity.py --variant libm: the platform libm in place of the deterministic version) */
+    return acosf(x);
+#endif
     if (!(fabsf(x) <= 1.0f))
         return NAN;
     const float PI_F = 0x1.921fb6p+1f, PIO2_F = 0x1.921fb6p+0f;

@@ -5,8 +5,10 @@ length^2 and round everything else twice -- "radiance differs from a real CUDA r
 This tool SAYS how many, for the contraction part of that difference: it renders the same frames with the oracle as built
 (-ffp-contract=off) and with the same sources built -ffp-contract=fast (`make -C oracle fmad`: gcc then fuses a*b+c within an
 expression, which is the rule nvcc follows) and compares them pixel by pixel.  It cannot see CUDA's libm (sinf / expf / powf
-differ from the deterministic polynomials by ulps as well) or cuRAND's seed constants.  CPU only.
-   python tools/fmad_sensitivity.py [scene] [W H spp depth]"""
+differ from the deterministic polynomials by ulps as well) or cuRAND's seed constants.  --variant=libm: the same
+comparison with the platform's libm in place of the deterministic polynomials (what ANOTHER libm, such as CUDA's, does to the
+frame); --variant=fmad_libm: both.  CPU only.
+   python tools/fmad_sensitivity.py [scene] [W H spp depth] [--variant=fmad|libm|fmad_libm]"""
 import json
 import os
 import subprocess
@@ -41,13 +43,15 @@ np.savez({out!r}, accum0=fr[0]['accum'], accum1=fr[1]['accum'], depth=fr[1]['dep
 
 
 def main():
-    scene = sys.argv[1] if len(sys.argv) > 1 else "cornell"
-    W, H, spp, depth = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (256, 256, 4, 4)
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all", "fmad"])
+    argv = [a for a in sys.argv[1:] if not a.startswith("--variant")]
+    variant = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")] or ["fmad"])[0]  # fmad | libm | fmad_libm
+    scene = argv[0] if len(argv) > 0 else "cornell"
+    W, H, spp, depth = (int(v) for v in argv[1:5]) if len(argv) > 4 else (256, 256, 4, 4)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all", "fmad", "libm"])
     with tempfile.TemporaryDirectory() as d:
         a = render(None, scene, W, H, spp, depth, os.path.join(d, "a.npz"))
-        b = render(os.path.join(ROOT, "oracle", "libptrt_oracle_fmad.so"), scene, W, H, spp, depth, os.path.join(d, "b.npz"))
-        out = {"scene": scene, "frame": f"{W}x{H} {spp} spp {depth} bounces, second of two consecutive frames", "pixels": W * H}
+        b = render(os.path.join(ROOT, "oracle", f"libptrt_oracle_{variant}.so"), scene, W, H, spp, depth, os.path.join(d, "b.npz"))
+        out = {"variant": variant, "scene": scene, "frame": f"{W}x{H} {spp} spp {depth} bounces, second of two consecutive frames", "pixels": W * H}
         out["object_id_differs_px"] = int((a["oid"] != b["oid"]).sum())
         out["depth_bits_differ_px"] = int((a["depth"].view(np.uint32) != b["depth"].view(np.uint32)).sum())
         dd = np.abs(a["depth"].astype(np.float64) - b["depth"]) / np.maximum(np.abs(a["depth"].astype(np.float64)), 1e-30)

@@ -220,7 +220,7 @@ def test_full_size_frames_equal_the_oracle(P, O, blue_noise, scene, spp, frames)
     s.close()
 
 
-@pytest.mark.parametrize("scene", ["cornell", "showcase", "cornell+post"])
+@pytest.mark.parametrize("scene", ["cornell", "showcase", "cornell+post", "cornell+tm"])
 def test_pipelined_frames_are_the_same_frames(P, scene):
     """Consecutive frames into ALTERNATING device targets overlap on the device (ptrt_set_option "pipeline", the default: a
     frame's launches follow the previous frame's launches of the same tile rows on auxiliary streams and do not wait for
@@ -235,7 +235,7 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
     def run(pipeline):
         s = P.Scene(W, H)
         build(s)
-        s.setPerfSamplesPerPixel(4 if scene == "cornell" else 2)  # (4 x 4: the overlapping Cornell frames run with lane refill)
+        s.setPerfSamplesPerPixel(4 if scene in ("cornell", "cornell+tm") else 2)  # (4 x 4: the overlapping Cornell frames run with lane refill)
         s.setMaxBounceDepth(4)
         s.setDenoiserEnabled(post)
         s.setBloomEnabled(post)
@@ -245,6 +245,9 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
         s.set_option("merged", 0)  # (no loop-shape sampling: it orders its frames behind the stream)
         s.set_option("pipeline", pipeline)
         s.set_option("persist", 2)  # (512 persistent waves: this small frame then has enough tiles per wave for lane refill)
+        if scene == "cornell+tm":  # the refill kernel's tonemap pass on a stream of the highest priority, its waves at s_setprio 3,
+            s.set_option("tm_prio", 3)      # and events around every launch (ptrt_launch_ms_history): same frames
+            s.set_option("time_launches", 1)
         tgt = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
         frames, flags = [], []
         for f in range(8):
@@ -252,7 +255,7 @@ def test_pipelined_frames_are_the_same_frames(P, scene):
                 s.moveCamera((0.3, 0.1, 5.0))  # host state only: the next frame still overlaps
             s.render_to_device(tgt[f & 1].data_ptr())
             flags.append(s.get_option("pipelined"))
-            assert s.get_option("refilled") == (1 if scene == "cornell" and flags[-1] else 0)
+            assert s.get_option("refilled") == (1 if scene in ("cornell", "cornell+tm") and flags[-1] else 0)
             if f in (2, 7):  # (reading back in between would order everything: only here)
                 s.sync()
                 frames.append((tgt[f & 1].cpu().numpy().copy(), s.read(P.BUF_ACCUM), s.read(P.BUF_RNG), s.stats()))

@@ -56,6 +56,8 @@ def build_scene(P, name, W, H, y0, rows, device, interleave=None):
         s.water_mesh, _ = P.scenes.fluid(s, cells=256, t=0.0)
     elif name == "million":
         P.scenes.million(s)
+    elif name in ("coincident", "coincident_tlas"):  # duplicated / coplanar / degenerate triangles (tests/test_hostile_geometry_gpu.py)
+        P.scenes.coincident(s, n=24, leaf=8 if name == "coincident" else 2)
     elif name == "matrix":  # the reference application's scene 10 (app_utils.cuh:729-795)
         P.scenes.material_matrix(s)
     else:

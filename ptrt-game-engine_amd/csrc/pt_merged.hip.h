@@ -216,6 +216,9 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                         vic = v | (ng << 8);
                         thief = true;
                         busy = active = true;
+                        if (!isany) {
+                            TS_EVENT(0);
+                        }
                     }
                 }
                 if (is_victim && vrank < k)
@@ -317,8 +320,10 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                     if (key != ~0ull) {
                         tb = __uint_as_float((uint32_t)(key >> 32));
                         sb = first + (int)(uint32_t)key;
-                        if (CSTEAL && thief && !(tcur < tb)) // a hit in front of its own leaf box: the reference may never have come here
+                        if (CSTEAL && thief && !(tcur < tb)) { // a hit in front of its own leaf box: the reference may never have come here
                             __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            TS_EVENT(1);
+                        }
                     }
                     pop();
                 }
@@ -331,8 +336,10 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 const unsigned long long key =
                     ((unsigned long long)__float_as_uint(tw) << 32) | ((unsigned long long)(uint32_t)oi << 24) | (uint32_t)sb;
                 const unsigned long long old = __hip_atomic_fetch_min(&L.best[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (CSTEAL && (old >> 24) == (key >> 24) && old != key) // two walks of one pair at the same distance
+                if (CSTEAL && (old >> 24) == (key >> 24) && old != key) { // two walks of one pair at the same distance
                     __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    TS_EVENT(2);
+                }
             }
             busy = false;
         }
@@ -378,8 +385,10 @@ PT_DEV void trace_merged(const KParams &K, const PairLds &L, int lane, bool ext,
         const unsigned long long dm = L.dirty[0];
         wave_sync();
         if (dm) {
-            TS_EVENT(3);
             const bool redo = ext_in && ((dm >> lane) & 1ull);
+            if (redo) {
+                TS_EVENT(3);
+            }
             if (redo)
                 L.best[lane] = ~0ull;
             int dummy = 0;

@@ -11,6 +11,7 @@
   fluid(scene, t)  dynamic height-field "water" over a static sphere "ship" (config 5).
   many(scene, n)   Cornell box + n small cubes and spheres, every third an instance with its own transform:
                    more meshes than one TLAS leaf holds (17), i.e. a TLAS with inner nodes.
+  coincident(scene) duplicated, coplanar and degenerate triangles: the cases in which first-found-wins decides.
 """
 import math
 
@@ -263,6 +264,53 @@ def many(scene, n=40, instanced=True, sphere_segments=5):
         else:
             scene.scale(m, tuple(rs.uniform(0.2, 0.5, 3)))
             scene.moveTo(m, pos)
+
+
+def _wall(n, z, half=3.0, dup=True):
+    """n x n axis-aligned quads at depth z; with `dup` every triangle twice."""
+    tris = []
+    xs = np.linspace(-half, half, n + 1, dtype=np.float32)
+    for j in range(n):
+        for i in range(n):
+            a, b = (xs[i], xs[j], z), (xs[i + 1], xs[j], z)
+            c, d = (xs[i + 1], xs[j + 1], z), (xs[i], xs[j + 1], z)
+            for t in ((a, b, c), (a, c, d)):
+                tris.extend([t, t] if dup else [t])
+    return tris
+
+
+def coincident(scene, n=5, leaf=8):
+    """Geometry in which the ORDER of the reference's traversal decides what is seen (intersection.cuh:247, :561: `t < best`,
+    strict -- of triangles at exactly the same distance the one found first wins) and its arithmetic leaves the ordinary
+    range (zero-area and collinear triangles: the |det| < 1e-6 reject, intersection.cuh:231).  Eight meshes; `leaf` is the
+    builder's leaf target for BLAS and TLAS alike (scene.cuh:556): 8 keeps the meshes in one TLAS leaf, 2 makes a real TLAS."""
+    red, blue = Material((0.8, 0.1, 0.1), 0.5), Material((0.1, 0.2, 0.9), 0.05, 1.0)
+    white, green = Material((0.73, 0.73, 0.73), 0.6), Material((0.1, 0.7, 0.2), 0.3)
+    glass = Material((0.95, 0.95, 0.95), 0.02, 0.0, transmission=1.0, ior=1.5)
+    p, q, r = (0.5, 0.5, -5.0), (1.5, 0.5, -5.0), (2.5, 0.5, -5.0)
+    junk = [(p, p, q), (p, q, r), (q, q, q),                                    # two equal vertices, collinear, a point
+            ((0.0, 0.0, -5.5), (1e-4, 0.0, -5.5), (0.0, 1e-4, -5.5)),           # |det| below the reference's 1e-6
+            ((-2.9, -2.9, -5.9), (2.9, -2.9, -5.9), (2.9, -2.9000001, -5.9))]   # a needle
+    scene.addTriangles(_wall(n, -6.0) + junk, red)  # every wall triangle twice: exact ties inside one BLAS
+    # the same triangles again as a second mesh with another material: exact ties ACROSS meshes -- the first mesh of the TLAS
+    # leaf wins in the reference, whatever order the pairs are walked in here
+    scene.addTriangles(_wall(n, -6.0, dup=False), blue)
+    # ... and once more with the other winding: the same plane, distances that differ in the last bits or not at all
+    scene.addTriangles([(c, b, a) for a, b, c in _wall(n, -6.0, dup=False)], green)
+    scene.addPlaneXZ(-3.0, 6.0, white)
+    scene.addPlaneXZ(-3.0, 6.0, green)  # coplanar floors: every floor hit is a tie, every shadow ray starts on both
+    box = scene.addCube(glass)          # its back face lies IN the wall's plane, its bottom face in the floors'
+    scene.scale(box, (2.0, 2.0, 2.0))
+    scene.moveTo(box, (-1.5, -2.0, -5.0))
+    inst = scene.addCube(green)         # an instance whose transform maps a face onto the wall's plane as well
+    scene.setPosition(inst, (1.5, 0.0, -5.5))
+    scene.setRotation(inst, (0.0, math.pi / 2, 0.0))
+    scene.setInstanceScale(inst, (1.0, 2.0, 1.0))
+    scene.addPointLight((0.0, 2.0, -3.0), (1.0, 0.9, 0.8), 40.0, 30.0, 0.0)
+    scene.addPointLight((2.0, -1.0, -6.0), (0.3, 0.5, 1.0), 30.0, 30.0, 0.25)  # IN the wall's plane: its shadow rays graze the triangles
+    scene.setSkyGradient((0.5, 0.7, 1.0), (1.0, 1.0, 1.0))
+    scene.setCamera((0.0, 0.0, 4.0), (0.0, 0.0, -6.0), (0.0, 1.0, 0.0), 45.0)
+    scene.setBVHLeafTarget(leaf, 0)
 
 
 # ---- the reference's dynamic-geometry caller (src/common/PTRTtransfer.cuh) ------------------------------------------------

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak check (GPU box, repo root): 24 consecutive 1080p frames with a wandering camera on four scenes, rendered
+"""Soak check (GPU box, repo root): 24 consecutive 1080p frames with a wandering camera on five scenes, rendered
 by the default traversal, by the plain one (batches of 64 pairs, every lane its own leaf, no stealing, no yield,
 one lane per pair), by the lock-step mesh loop and (PMODE 1) by the lane-refill kernel; every frame's HDR image, object ids, generator states and ray
 counts must be identical.  (tests/test_misc_gpu.py holds the two-frame version with the async and wavefront
@@ -22,7 +22,9 @@ def frames(build, opts, n, spp):
     s.close(); return out
 plain = dict(fetch_min=0, leaf_pairs=0, steal=0, csteal=0, leaf_min=64, pair_split=0)
 for name, build, spp in (("showcase", P.scenes.showcase, 4), ("fluid", lambda s: P.scenes.fluid(s, cells=256, t=0.7), 2),
-                         ("many", lambda s: _many_meshes(P, s, n=60), 4), ("cornell", P.scenes.cornell, 4)):
+                         ("many", lambda s: _many_meshes(P, s, n=60), 4), ("cornell", P.scenes.cornell, 4),
+                         # duplicated / coplanar / degenerate triangles: first-found-wins decides, ~1 ray in 100 marked by a thief
+                         ("coincident", lambda s: P.scenes.coincident(s, n=24, leaf=8), 4)):
     a = frames(build, {}, 24, spp); b = frames(build, plain, 24, spp); c = frames(build, dict(pair_trace=0), 24, spp)
     d = frames(build, dict(refill=2, persist=7), 24, spp)  # (PMODE 1: persistent waves with lane refill, 1,792 of them for 32,400 tiles)
     e = frames(build, dict(sample_sync=0), 24, spp)        # (every lane at its own pace; the default at 4 bounces keeps the samples in step)

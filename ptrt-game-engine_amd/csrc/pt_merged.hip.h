@@ -230,7 +230,7 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
         const int yield_n = csteal ? K.csteal : K.steal, leaf_min = csteal ? K.csteal_leaf_min : K.leaf_min;
         // ---- inner nodes: wave-uniform loop with a predicated step; ends once K.leaf_min lanes wait at a leaf, or
         // after K.steal steps while idle lanes wait for stack entries to take
-        TS_ADD(11, t_it);
+        TS_ADDQ(11, t_it);
         const unsigned long long t_nd = TS_NOW();
         int steps = 0;
         for (;;) {
@@ -269,7 +269,7 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 }
             }
         }
-        TS_ADD(9, t_nd);
+        TS_ADDQ(9, t_nd);
         const unsigned long long t_lf = TS_NOW();
         // ---- leaf phase as compacted (lane, triangle) tests (see run_closest_queue); a test sees its lane's limit
         // at leaf entry and merges with a 64-bit LDS min on {t bits, index in leaf}
@@ -329,7 +329,7 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
                 }
             }
         }
-        TS_ADD(10, t_lf);
+        TS_ADDQ(10, t_lf);
         if (busy && !active) { // this pair is finished: a closest-hit pair merges into its ray
             if (!isany && sb >= 0) {
                 const float tw = xf ? tb / dirScale : tb;
@@ -348,7 +348,7 @@ PT_DEV void run_merged_queue(const KParams &K, const PairLds &L, int lane, int P
     ts.v[0] = lane == 0 ? 1u : 0u;
     ts.v[1] = lane == 0 ? (unsigned)P : 0u;
 #endif
-    TS_ADD(8, t_run);
+    TS_ADDQ(8, t_run);
     ts.flush(0, lane, L.stat_bounce);
 }
 

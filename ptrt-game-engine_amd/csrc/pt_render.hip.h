@@ -246,7 +246,19 @@ struct CycleAcc {
 #define TS_NOW() __builtin_readcyclecounter()
 #define TS_ADD(slot, t) (cyc.c[(slot) - 8] += __builtin_readcyclecounter() - (t))
 #define TS_ADDL(slot, t) (L.cyc->c[(slot) - 8] += __builtin_readcyclecounter() - (t))
+// slots 8..11 hold the traversal queues' parts (queue run, node loops, leaf blocks, any-hit run) -- or, in a build with
+// -DPT_TS_SHADING as well, the shading phases [A] / [C] / [C2] / [E] of every loop shape (PMODE 1, which has no queues, always)
+#ifdef PT_TS_SHADING
+constexpr bool TS_SHADING = true;
 #else
+constexpr bool TS_SHADING = false;
+#endif
+#define TS_ADDQ(slot, t) do { if (!TS_SHADING) TS_ADD(slot, t); } while (0)
+#define TS_ADDLQ(slot, t) do { if (!TS_SHADING) TS_ADDL(slot, t); } while (0)
+#else
+constexpr bool TS_SHADING = false;
+#define TS_ADDQ(slot, t) (void)(t)
+#define TS_ADDLQ(slot, t) (void)(t)
 struct TravStats {
     PT_DEV void flush(int, int, int = -1) {}
 };
@@ -794,7 +806,7 @@ template <int GEN, bool STEAL = false> PT_DEV void run_closest_queue(const KPara
                 }
             }
         }
-        TS_ADDL(9, t_nd);
+        TS_ADDLQ(9, t_nd);
         const unsigned long long t_lf = TS_NOW();
         const bool atleaf = active && cur < 0;
         if (STEAL && !__builtin_amdgcn_ballot_w64(atleaf)) {
@@ -887,7 +899,7 @@ template <int GEN, bool STEAL = false> PT_DEV void run_closest_queue(const KPara
                 __hip_atomic_fetch_or(L.dirty, 1ull << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pop();
         }
-        TS_ADDL(10, t_lf);
+        TS_ADDLQ(10, t_lf);
         if (busy && !active) { // this pair is finished: merge it into its ray
             if (sb >= 0) {
                 const float tw = xf ? tb / dirScale : tb;
@@ -938,7 +950,7 @@ PT_DEV Hit closest_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, b
         run_closest_queue<false, true>(K, L, lane, P, o, d);
     else
         run_closest_queue<false>(K, L, lane, P, o, d);
-    TS_ADDL(8, t_q);
+    TS_ADDLQ(8, t_q);
     wave_sync();
     if (stealing) {
         // rays a thief could not vouch for (run_closest_queue): traced again, every pair walked by one lane
@@ -1190,7 +1202,7 @@ PT_DEV bool any_hit_pairs_dyn(const KParams &K, const PairLds &L, int lane, bool
     wave_sync();
     const unsigned long long t_q = TS_NOW();
     run_any_queue<false>(K, L, lane, P, o, d);
-    TS_ADDL(11, t_q);
+    TS_ADDLQ(11, t_q);
     wave_sync();
     const bool occluded = alive && (L.occ[lane] != 0u);
     wave_sync();
@@ -1357,7 +1369,7 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
                 }
             }
             need_pop = has;
-            TS_ADD(9, t_walk);
+            TS_ADDQ(9, t_walk);
             // a lane's k-th leaf of this fill sits in slot k (lanes that found none keep their count)
             const int slot = ns;
             if (has) {
@@ -1375,7 +1387,7 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
                 break;
             const unsigned long long t_b = TS_NOW();
             base = build_pairs_general<false>(K, L, lane, has, lf, w, T_FAR, slot, base);
-            TS_ADD(10, t_b);
+            TS_ADDQ(10, t_b);
             if (base >= TLAS_FILL_TARGET)
                 break;
         }
@@ -1385,7 +1397,7 @@ PT_DEV Hit closest_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, 
         const unsigned long long t_q = TS_NOW();
         run_closest_queue<true>(K, L, lane, base, o, d);
         wave_sync();
-        TS_ADD(8, t_q);
+        TS_ADDQ(8, t_q);
 #ifdef PT_TRAV_STATS
         cyc.c[3] += 1; // fills (closest)
 #endif
@@ -1463,7 +1475,7 @@ PT_DEV bool any_hit_pairs_tlas_rounds(const KParams &K, const PairLds &L, int la
                 }
             }
             need_pop = has;
-            TS_ADD(9, t_walk);
+            TS_ADDQ(9, t_walk);
             if (has)
                 L.leafx[step * 64 + lane] = lf.x; // (every lane uses slot `step` here: no per-slot results to keep apart)
             if (!__builtin_amdgcn_ballot_w64(has))
@@ -1471,7 +1483,7 @@ PT_DEV bool any_hit_pairs_tlas_rounds(const KParams &K, const PairLds &L, int la
             any_leaf = true;
             const unsigned long long t_b = TS_NOW();
             base = build_pairs_general<true>(K, L, lane, has, lf, w, tMax, step, base);
-            TS_ADD(10, t_b);
+            TS_ADDQ(10, t_b);
             if (base >= TLAS_FILL_TARGET)
                 break;
         }
@@ -1481,7 +1493,7 @@ PT_DEV bool any_hit_pairs_tlas_rounds(const KParams &K, const PairLds &L, int la
         const unsigned long long t_q = TS_NOW();
         run_any_queue<1>(K, L, lane, base, o, d);
         wave_sync();
-        TS_ADD(8, t_q);
+        TS_ADDQ(8, t_q);
 #ifdef PT_TRAV_STATS
         cyc.c[7] += 1; // fills (any)
 #endif
@@ -1556,13 +1568,13 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
                     }
                 }
                 need_pop = has;
-                TS_ADD(9, t_walk);
+                TS_ADDQ(9, t_walk);
                 if (!__builtin_amdgcn_ballot_w64(has))
                     break;
                 const unsigned long long t_b = TS_NOW();
                 mask = root_masks<true>(K, lane, has, lf, w, tMax);
                 first = lf.x;
-                TS_ADD(10, t_b);
+                TS_ADDQ(10, t_b);
             }
             // hits of this leaf over the wave (a lane has at most 32): bit planes of the lanes' counts
             int total = 0;
@@ -1586,7 +1598,7 @@ PT_DEV bool any_hit_pairs_tlas(const KParams &K, const PairLds &L, int lane, boo
         const unsigned long long t_q = TS_NOW();
         run_any_queue<2>(K, L, lane, base, o, d);
         wave_sync();
-        TS_ADD(8, t_q);
+        TS_ADDQ(8, t_q);
 #ifdef PT_TRAV_STATS
         cyc.c[7] += 1; // fills (any)
 #endif
@@ -2039,7 +2051,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             fresh = false;
         }
 
-        if (PMODE == 1)
+        if (PMODE == 1 || TS_SHADING)
             TS_ADD(8, t_pa);
         const bool act = live && !fresh; // (has a ray: every live lane, unless K.sample_sync keeps it waiting)
 #ifdef PT_TRAV_STATS
@@ -2217,7 +2229,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             n_shadow += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_shadow));
         }
 
-        if (PMODE == 1)
+        if (PMODE == 1 || TS_SHADING)
             TS_ADD(9, t_pc);
         PT_MARK("C2");
         phase_prio<PMODE, 3, 2>();
@@ -2263,7 +2275,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
                 }
             }
         }
-        if (PMODE == 1)
+        if (PMODE == 1 || TS_SHADING)
             TS_ADD(10, t_pc2);
         TS_LANES(21, lit);
         PT_MARK("D");
@@ -2342,7 +2354,7 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
             ++sb; // ++s
             fresh = true;
         }
-        if (PMODE == 1)
+        if (PMODE == 1 || TS_SHADING)
             TS_ADD(11, t_pe);
     }
 

@@ -90,7 +90,8 @@ if cy[14]:  # instrumented build: where a wave's cycles go (s_memtime, summed ov
     pct = lambda k: 100.0 * cy[k] / tot
     print(f"wave cycles {tot:.4g}: closest-hit (or merged) trace {pct(12):.1f} %, shadow trace {pct(13):.1f} %, "
           f"everything else {100.0 - pct(12) - pct(13):.1f} %")
-    if scene == "cornell":  # PMODE 1 has no queues: its build spends those slots on the shading phases
+    if scene == "cornell" or os.environ.get("PT_TS_SHADING"):  # PMODE 1 has no queues: its build spends those slots on the shading
+                                                               # phases; so does a -DPT_TS_SHADING build for every loop shape
         print(f"   shading: [A] regenerate {pct(8):.1f} %, [C] surface + light sample {pct(9):.1f} %, [C2] BSDF of the light sample "
               f"{pct(10):.1f} %, [E] scatter {pct(11):.1f} %, [R] refill {pct(15):.1f} %")
     else:

@@ -776,6 +776,15 @@ template <int GEN, bool STEAL = false> PT_DEV void run_closest_queue(const KPara
                 break;
             if (STEAL && can_steal && ++steps > K.csteal) // idle lanes are waiting for stack entries to take
                 break;
+#ifdef PT_TRAV_STATS
+            {   // what the lanes that take no node step in this wave-iteration are doing: waiting at a leaf / without a walk
+                const unsigned long long wl = __builtin_amdgcn_ballot_w64(active && cur < 0), il = __builtin_amdgcn_ballot_w64(!active);
+                if (lane == 0) {
+                    atomicAdd(&g_trav_dbg[1025 + 4], (unsigned long long)__builtin_popcountll(wl));
+                    atomicAdd(&g_trav_dbg[1025 + 5], (unsigned long long)__builtin_popcountll(il));
+                }
+            }
+#endif
             if (innode) {
                 TS_WAVE(2);
                 TS_LANE(3);

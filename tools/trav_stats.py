@@ -68,6 +68,10 @@ if hasattr(P.lib, "ptrt_debug_trav_dbg"):
     if any(ev):
         print(f"closest-hit stealing: {ev[0]} subtrees stolen; {ev[3]} rays traced again without it ({ev[1]} marks for a thief's hit in front of "
               f"its leaf box, {ev[2]} for equal distances from two walks of one pair)")
+    if ev[4] or ev[5]:
+        nw_c = v[2]
+        print(f"   closest node loop, lanes per wave-iteration that take no step: {ev[4] / max(1, nw_c):.1f} wait at a leaf, "
+              f"{ev[5] / max(1, nw_c):.1f} have no walk (separate phases' queue only)")
     if os.environ.get("PT_DBG"):
         f32 = lambda u: struct.unpack("f", struct.pack("I", u & 0xffffffff))[0]
         print("debug records:", dbg[1024])

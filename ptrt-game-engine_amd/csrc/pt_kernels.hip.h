@@ -110,6 +110,7 @@ struct KParams {
                           // split_i, split_i + split_n, ...
     int spp, max_depth, frame_count;
     int sample_sync; // 1: the lanes of a wave start their samples together (path_trace_kernel [A])
+    int tile_run;    // option "tile_run": workgroup -> tile map of the one-tile kernels, see path_trace_kernel (0: workgroup k renders tile k)
     // buffers (tile-sized)
     uint32_t *rng;    // 6 planes of rng_plane words (the context's rows*width; larger than the frame at a reduced render size)
     size_t rng_plane;

@@ -1750,7 +1750,26 @@ __global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(waves_p
     // finished its pixel takes the next one of the launch -- [R] in the loop below -- instead of idling until the slowest
     // pixel of its 8x8 tile is done (tools/trav_stats.py: 18 % of the lane-iterations of a 1080p Cornell frame).
     static_assert(!STREAM || WG == 1, "lane refill: one-wave workgroups");
-    const int tile = WG > 1 ? blockIdx.x * WG + wave : blockIdx.x;
+    // K.tile_run (one-tile workgroups): XCD-aware order.  The dispatcher deals consecutive workgroups to the eight XCDs in turn, so
+    // by number each XCD -- each with an L2 of its own -- renders every eighth tile of a row and all eight fetch the same nodes
+    // and triangles.  Instead, of every 8 * run consecutive tiles XCD x takes tiles [x * run, (x + 1) * run): neighbours, whose
+    // rays walk the same part of the trees, share an L2.  Runs of 8 (64 x 8 pixels): fluid frame 0.888 -> 0.860 ms alone, 0.813 ->
+    // 0.791 overlapping, with its refit 0.941 -> 0.913; showcase 3.45 -> 3.42 / 3.18 -> 3.14, at 4K 24.5 -> 24.1; 4 and 16 are within
+    // half a percent of 8, 2 gains half as much; blocks of 4 x 2 .. 8 x 8 tiles per XCD instead of runs lose 1 .. 9 %, whole
+    // vertical stripes per XCD 10 % (the XCDs' shares of the work differ).  What else was measured about the ORDER of the tiles, all slower than by number, because
+    // the ~5,000 tiles in flight stop being neighbours: bottom-up +13 % (showcase) / +28 % (fluid), every tile at random +32 / +42 %,
+    // blocks of 32 at random +26 / +39 %, rows from top and bottom in turn +25 / +47 %, rows with a stride of 4 / 8 / 16 +23..33 %
+    // / +34..43 %, Z-order +4 / +16 %; and the dearest tiles of an earlier frame first (timed per tile, counting-sorted into 256
+    // classes on the device): -3 % for a frame alone on the chip, whose tail it shortens, +4 % for overlapping fluid frames --
+    // per 32-tile block instead of per tile +15 %: a launch whose resident waves all start in step stays in step.
+    // (A trailing run of fewer than 8 * run tiles keeps its numbers.)
+    int tile_sel = (int)blockIdx.x;
+    if (!STREAM && WG == 1 && K.tile_run > 0) {
+        const int span = 8 * K.tile_run, chunk = (int)blockIdx.x / span, in = (int)blockIdx.x % span;
+        if ((chunk + 1) * span <= (int)gridDim.x)
+            tile_sel = chunk * span + (in % 8) * K.tile_run + in / 8;
+    }
+    const int tile = WG > 1 ? blockIdx.x * WG + wave : tile_sel;
     // (a larger workgroup's last tiles may not exist: such a wave takes part in the staging and the barrier with a tile
     // outside the frame -- `inside` is false for all its lanes -- and leaves before the loop)
     const bool no_tile = WG > 1 && tile >= K.n_tiles;

@@ -26,6 +26,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -182,6 +183,7 @@ struct ptrt_ctx {
     unsigned int *d_queue = nullptr; // {ticket, waves out} per launch lane: [0] the stream, [1 + i] auxiliary stream i
     int sample_sync = -1;            // option "sample_sync": -1 (default) where it was measured to pay, 0 never, 1 always (ptrt_render)
     int sample_sync_eff = 0;         // ... the last frame
+    int tile_run = 8;                // option "tile_run": of every 8 * run consecutive tiles XCD x renders a run of neighbours (path_trace_kernel); 0: tile k on workgroup k
     int ticket_tiles = 1;            // option "ticket_tiles": consecutive tiles per ticket of the queue
     int persist = 0, n_cus = 0;      // option "persist": persistent waves per CU (0 = the variant's occupancy)
     int as_blocks[2] = {0, 0}; // resident workgroups of the <false>/<true> kernel at as_lds bytes of LDS
@@ -640,6 +642,7 @@ pt::KParams make_params(ptrt_ctx *c) {
     K.object_id = scaled ? c->s_object_id : c->d_object_id;
     K.rgb8 = c->d_rgb8;
     K.counters = nullptr;
+    K.tile_run = 0;
     return K;
 }
 
@@ -2526,6 +2529,7 @@ int ptrt_render(ptrt_ctx *c, int frame_index, int spp, int max_depth, void *out_
     // (when few are still under way, or when many wait) was measured at every threshold and is worse than both extremes.
     K.sample_sync = c->sample_sync >= 0 ? c->sample_sync : (max_depth <= 4 ? 1 : 0);
     c->sample_sync_eff = K.sample_sync;
+    K.tile_run = c->tile_run;
     K.frame_count = frame_index;
     unsigned char *frame_rgb8 = (out_rgb8 && out_is_device) ? (unsigned char *)out_rgb8 : c->d_rgb8;
     // the stage that produces the final HDR image also tonemaps it; earlier stages skip theirs
@@ -3179,6 +3183,11 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
         c->persist = value < 0 ? 0 : value;
     else if (n == "sample_sync")
         c->sample_sync = value < 0 ? -1 : (value != 0);
+    else if (n == "tile_run") {
+        if (value < 0 || value > 64)
+            return fail(c, PTRT_E_INVALID, "tile_run: 0 (tile k on workgroup k) or the tiles per XCD and run, 1..64");
+        c->tile_run = value;
+    }
     else if (n == "ticket_tiles")
         c->ticket_tiles = value < 1 ? 1 : (value > 16 ? 16 : (int)value);
     else if (n == "refill")
@@ -3190,7 +3199,7 @@ int ptrt_set_option(ptrt_ctx *c, const char *name, long long value) {
     } else if (n == "tlas_rounds") // PMODE 3 shadow rays: one TLAS leaf per ray and fill instead of all of them (A/B, tests)
         c->tlas_rounds = value ? 1 : 0;
     else if (n == "pm1_wg") { // PMODE 1: one or two tiles per workgroup (0 = choose by the LDS budget; A/B, tests)
-        if (value < 0 || value > 2)
+        if (value < 0 || value > 20)
             return fail(c, PTRT_E_INVALID, "pm1_wg must be 0..2");
         c->pm1_wg = (int)value;
     }
@@ -3235,7 +3244,7 @@ int ptrt_get_option(ptrt_ctx *c, const char *name, long long *value) {
     const std::pair<const char *, long long> tab[] = {
         {"count_rays", c->count_rays}, {"force_geom", c->force_geom}, {"force_full", c->force_full}, {"pair_trace", c->pair_trace},
         {"steal", c->steal}, {"csteal", c->csteal}, {"csteal_min", c->csteal_min}, {"csteal_follow", c->csteal_follow}, {"atrous_exp", c->atrous_exp}, {"csteal_leaf_min", c->csteal_leaf_min}, {"lds_nodes", c->lds_nodes}, {"merged", c->merged}, {"leaf_pairs", c->leaf_pairs}, {"lds_pad", c->lds_pad},
-        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"time_launches", c->time_launches}, {"tm_prio", c->tm_prio}, {"persist", c->persist}, {"refill", c->refill}, {"sample_sync", c->sample_sync}, {"sample_sync_eff", c->sample_sync_eff}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
+        {"stage", c->stage}, {"pm1_wg", c->pm1_wg}, {"tlas_rounds", c->tlas_rounds}, {"time_kernels", c->time_kernels}, {"time_launches", c->time_launches}, {"tm_prio", c->tm_prio}, {"persist", c->persist}, {"refill", c->refill}, {"sample_sync", c->sample_sync}, {"sample_sync_eff", c->sample_sync_eff}, {"tile_run", c->tile_run}, {"ticket_tiles", c->ticket_tiles}, {"refilled", c->refill_eff ? 1 : 0}, {"split", c->split}, {"split_eff", c->split_eff}, {"pipeline", c->pipeline}, {"pipelined", c->pipelined_last ? 1 : 0}, {"pair_split", c->pair_split}, {"async_lanes", c->async_lanes}, {"shade_min", c->shade_min},
         {"leaf_min", c->leaf_min}, {"wavefront", c->wavefront}, {"wf_sort", c->wf_sort}, {"fetch_min", c->fetch_min}, {"denoiser_active", c->dn_active},
         {"motion_vectors", c->mv_active}, {"use_graphs", c->use_graphs},
         // read-only: the last launch

@@ -193,7 +193,8 @@ def test_full_size_traversal_variants_agree(P, scene):
     # refill=2: PMODE 1 as persistent waves whose lanes draw the next pixel of the launch (the default for overlapping frames)
     # tlas_rounds=1: shadow rays behind a real TLAS take one leaf per fill (the path of scenes with more than 1024 meshes)
     # csteal: closest-hit subtree stealing with verification (PMODE 2's default) off / at its most eager / without the thieves following their victims' limits
-    for opts in (dict(merged=1), dict(merged=1, csteal=0), dict(merged=1, steal=1, csteal=1), dict(merged=0, csteal=0), dict(merged=0, csteal=1, csteal_leaf_min=4), dict(merged=0, csteal=3, csteal_min=4, csteal_follow=0), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1), dict(refill=2), dict(sample_sync=0), dict(sample_sync=1), dict(sample_sync=1, refill=2)):
+    # tile_run: the one-tile kernels' workgroup -> tile map (default: of every 64 tiles each XCD renders 8 neighbours): tile k on workgroup k / runs of 3
+    for opts in (dict(tile_run=0), dict(tile_run=3), dict(merged=1), dict(merged=1, csteal=0), dict(merged=1, steal=1, csteal=1), dict(merged=0, csteal=0), dict(merged=0, csteal=1, csteal_leaf_min=4), dict(merged=0, csteal=3, csteal_min=4, csteal_follow=0), dict(lds_nodes=1), plain, dict(pair_trace=0), dict(async_lanes=1), dict(wavefront=1), dict(pm1_wg=2), dict(tlas_rounds=1), dict(refill=2), dict(sample_sync=0), dict(sample_sync=1), dict(sample_sync=1, refill=2)):
         got = _frames(P, build, opts, spp=spp)
         for f, (a, b) in enumerate(zip(ref, got)):
             for k in ("accum", "normal", "depth", "object_id", "rgb8", "rng"):

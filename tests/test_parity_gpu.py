@@ -280,6 +280,24 @@ def test_tiny_and_ragged_frames(P, O, blue_noise, size):
         s.close()
 
 
+@pytest.mark.parametrize("size", [(100, 60), (520, 24), (64, 520)])
+@pytest.mark.parametrize("run", [0, 1, 3, 8, 64])
+def test_workgroup_to_tile_maps_cover_the_frame(P, O, blue_noise, size, run):
+    """Option tile_run (path_trace_kernel: of every 8 * run consecutive tiles workgroup p renders the tile XCD p % 8's run holds):
+    a permutation of the launch's tiles whatever the frame's size -- launches of fewer tiles than one span, spans that cross
+    rows of tiles, a trailing part that keeps its numbers --, so every pixel is rendered exactly once: the oracle's frame."""
+    for build, opts in ((P.scenes.cornell, {}), (lambda s: P.scenes.showcase(s, segments=6), dict(merged=0)),
+                        (lambda s: P.scenes.showcase(s, segments=6), dict(merged=1))):
+        s = P.Scene(*size)
+        build(s)
+        s.set_option("tile_run", run)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        gpu, cpu = render_both(P, O, s, blue_noise, 1, 3, 1)
+        assert_frames_equal(gpu, cpu)
+        s.close()
+
+
 def test_maximum_samples_and_bounces(P, O, blue_noise):
     """samplesPerPixel and maxBounceDepth at the setters' upper clamp (16, scene.cuh:1894-1897), a scene without
     lights (no light sampling at all) and one without sky."""

@@ -540,7 +540,8 @@ void ptrt_farm_destroy(ptrt_farm *farm);
  *   tile_run 0..64        the one-tile-per-workgroup kernels' workgroup -> tile map.  Consecutive workgroups go to the eight XCDs in
  *                         turn; with n > 0, of every 8 n consecutive tiles XCD x renders tiles [x n, (x + 1) n) -- neighbours,
  *                         whose rays walk the same part of the trees, share an L2 -- instead of every eighth tile.  8 (default):
- *                         the fluid frame 0.941 -> 0.913 ms, showcase 3.18 -> 3.14, at 4K 24.5 -> 24.1; 0: tile k on workgroup k.
+ *                         the fluid frame 0.941 -> 0.913 ms with a quarter of its L2 misses, showcase 3.18 -> 3.14, at 4K 24.5 -> 24.1
+ *                         (4 .. 32 are within one percent of each other from 720p to 4K); 0: tile k on workgroup k.
  *                         Same bits (a permutation of independent tiles).
  *   tlas_rounds 0|1       real TLAS: shadow rays take one TLAS leaf per fill of the pair list (what > 1024 meshes use) instead of all
  *   pm1_wg 0|1|2          PMODE 1: tiles per workgroup (1 default; 2: two tiles share the LDS copies, six waves per SIMD; 0: 2 if it fits)

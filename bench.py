@@ -535,6 +535,12 @@ def main():
         # initialised the GPU, and a child keeps this one free to relay), relays rank 0's line and exits with the child's code.
         sys.exit(spawn_ranks(args.gpus))
 
+    if args.gpus > 1:
+        # One rank holds the context's stream, its two auxiliary streams, torch's and RCCL's own.  The runtime maps streams onto
+        # GPU_MAX_HW_QUEUES (4) hardware queues, and a queue is in order: a packet that waits -- a gather waiting for its peers --
+        # holds back whatever another stream put behind it on the same queue (seen on one GPU as two launches of a frame
+        # running one after the other).  Eight queues: one per stream.  Must be set before HIP starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import ptrt_amd as P
 

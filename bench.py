@@ -537,9 +537,8 @@ def main():
 
     if args.gpus > 1:
         # One rank holds the context's stream, its two auxiliary streams, torch's and RCCL's own.  The runtime maps streams onto
-        # GPU_MAX_HW_QUEUES (4) hardware queues, and a queue is in order: a packet that waits -- a gather waiting for its peers --
-        # holds back whatever another stream put behind it on the same queue (seen on one GPU as two launches of a frame
-        # running one after the other).  Eight queues: one per stream.  Must be set before HIP starts.
+        # GPU_MAX_HW_QUEUES (4) in-order hardware queues; two launches of a frame that end up on one queue run one after the other
+        # (seen once on one GPU with a fourth busy stream).  Eight queues: room for all.  Set before HIP starts.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import ptrt_amd as P

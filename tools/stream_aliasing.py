@@ -14,18 +14,25 @@ torch.cuda.set_device(0)
 import ptrt_amd as P  # noqa: E402
 from bench import CONFIGS, build_scene  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "showcase1080"
-counts = [int(v) for v in sys.argv[2:]] or [0, 1, 2, 3, 4, 6, 8]
+late = "--late" in sys.argv  # create the extra streams AFTER the context has rendered overlapping frames (its streams exist and have run)
+argv = [a for a in sys.argv if a != "--late"]
+name = argv[1] if len(argv) > 1 else "showcase1080"
+counts = [int(v) for v in argv[2:]] or [0, 1, 2, 3, 4, 6, 8]
 cfg = CONFIGS[name]
 W, H = cfg["width"], cfg["height"]
 extra = []
-for k in counts:
+def more(k):
     while len(extra) < k:
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
             torch.zeros(16, device="cuda").add_(1)
         extra.append(st)
     torch.cuda.synchronize()
+
+
+for k in counts:
+    if not late:
+        more(k)
     s = build_scene(P, cfg["scene"], W, H, 0, 0, 0)
     s.setPerfSamplesPerPixel(cfg["spp"])
     s.setMaxBounceDepth(cfg["depth"])
@@ -35,12 +42,17 @@ for k in counts:
     for f in range(40):
         s.render_to_device(tgt[f & 1].data_ptr())
     torch.cuda.synchronize()
+    if late:
+        more(k)
+        for f in range(8):
+            s.render_to_device(tgt[f & 1].data_ptr())
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 60
     for f in range(n):
         s.render_to_device(tgt[f & 1].data_ptr())
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
-    print(f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', '(default)')}  {name}: {k} extra streams -> {ms:.4f} ms/frame "
+    print(f"{'late ' if late else ''}GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', '(default)')}  {name}: {k} extra streams -> {ms:.4f} ms/frame "
           f"(pipelined {s.get_option('pipelined')}, split {s.get_option('split_eff')})", flush=True)
     s.close()
